@@ -1,0 +1,138 @@
+// Generic FP64 GEMM on the 4x4x4 matrix-core instruction (see mma_f64.h): 128x128 tile per 256-thread
+// workgroup, 16-deep k-chunks double-buffered through LDS, two workgroups per CU.
+// Used by the global step (M x M algebra) and, through the same building blocks, by the phase kernels.
+#include "gp_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace gp {
+
+template <Layout LA, Layout LB>
+__global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.tri == 1 && bx > by) return;
+  if (p.tri == 2 && bx < by) return;
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * WT, wcol0 = (wave & 1) * WT;
+  const double* A = p.A + (long)bz * p.sA;
+  const double* B = p.B + (long)bz * p.sB;
+  double* C = p.C + (long)bz * p.sC;
+  const long row0 = (long)by * TILE, col0 = (long)bx * TILE;
+  const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda : A + row0;
+  const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb : B + col0;
+  const long a_step = (LA == K_CONTIG) ? KC : (long)KC * p.lda;
+  const long b_step = (LB == K_CONTIG) ? KC : (long)KC * p.ldb;
+  const int nc = p.K / KC;
+
+  Acc acc;
+  acc.zero();
+  const LaneOfs ofs = lane_offsets<LA, LB>(wrow0, wcol0, lane);
+  tile_dma<LA>(lds[0][0], Ab, p.lda, wave, lane);
+  tile_dma<LB>(lds[0][1], Bb, p.ldb, wave, lane);
+  dma_wait();
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nc) {
+      tile_dma<LA>(lds[cur ^ 1][0], Ab + (long)(c + 1) * a_step, p.lda, wave, lane);
+      tile_dma<LB>(lds[cur ^ 1][1], Bb + (long)(c + 1) * b_step, p.ldb, wave, lane);
+    }
+    mma_chunk<LA, LB>(lds[cur][0], lds[cur][1], acc, ofs);
+    dma_wait();
+    __syncthreads();
+  }
+  mfma_drain(acc.v[3][15]);
+  if (p.beta != 0.0) {
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+      for (int bc = 0; bc < 16; ++bc) {
+        const long r = row0 + wrow0 + acc_row(ar, lane), cc = col0 + wcol0 + acc_col(bc, lane);
+        C[r * p.ldc + cc] = p.alpha * acc.v[ar][bc] + p.beta * C[r * p.ldc + cc];
+      }
+  } else {
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+      for (int bc = 0; bc < 16; ++bc) {
+        const long r = row0 + wrow0 + acc_row(ar, lane), cc = col0 + wcol0 + acc_col(bc, lane);
+        C[r * p.ldc + cc] = p.alpha * acc.v[ar][bc];
+      }
+  }
+}
+
+void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p) {
+  dim3 grid(n / TILE, m / TILE, batch), block(256);
+  if (la == K_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<K_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
+  else if (la == K_CONTIG && lb == K_CONTIG) hipLaunchKernelGGL((gemm128_kernel<K_CONTIG, K_CONTIG>), grid, block, 0, st, p);
+  else if (la == FREE_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, K_CONTIG>), grid, block, 0, st, p);
+}
+
+}  // namespace gp
+
+// ---- test hook -------------------------------------------------------------------------------------------------
+extern "C" int gp_debug_gemm(int device, int ta, int tb, int m, int n, int k, double alpha, const double* A, const double* B,
+                             double beta, double* C) {
+  using namespace gp;
+  gp_ctx* ctx = nullptr;
+  if (m <= 0 || n <= 0 || k <= 0 || !A || !B || !C) return fail(ctx, GP_ERR_BAD_ARG, "gp_debug_gemm: bad argument");
+  GP_HIP(ctx, hipSetDevice(device));
+  const long mp = round_up(m, TILE), np = round_up(n, TILE), kp = round_up(k, KC);
+  // A stored (m,k) row-major [K_CONTIG] or (k,m) [FREE_CONTIG]; B stored (k,n) [FREE_CONTIG] or (n,k) [K_CONTIG]
+  const long a_rows = ta ? kp : mp, a_cols = ta ? mp : kp, b_rows = tb ? np : kp, b_cols = tb ? kp : np;
+  std::vector<double> hA(a_rows * a_cols, 0.0), hB(b_rows * b_cols, 0.0), hC(mp * np, 0.0);
+  const long ar = ta ? k : m, ac = ta ? m : k, br = tb ? n : k, bc = tb ? k : n;
+  for (long i = 0; i < ar; ++i) for (long j = 0; j < ac; ++j) hA[i * a_cols + j] = A[i * ac + j];
+  for (long i = 0; i < br; ++i) for (long j = 0; j < bc; ++j) hB[i * b_cols + j] = B[i * bc + j];
+  for (long i = 0; i < m; ++i) for (long j = 0; j < n; ++j) hC[i * np + j] = C[i * n + j];
+  double *dA, *dB, *dC;
+  GP_HIP(ctx, hipMalloc(&dA, hA.size() * 8));
+  GP_HIP(ctx, hipMalloc(&dB, hB.size() * 8));
+  GP_HIP(ctx, hipMalloc(&dC, hC.size() * 8));
+  GP_HIP(ctx, hipMemcpy(dA, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
+  GP_HIP(ctx, hipMemcpy(dB, hB.data(), hB.size() * 8, hipMemcpyHostToDevice));
+  GP_HIP(ctx, hipMemcpy(dC, hC.data(), hC.size() * 8, hipMemcpyHostToDevice));
+  GemmP p{dA, dB, dC, a_cols, b_cols, np, 0, 0, 0, (int)kp, alpha, beta, 0};
+  launch_gemm(nullptr, ta ? FREE_CONTIG : K_CONTIG, tb ? K_CONTIG : FREE_CONTIG, (int)mp, (int)np, 1, p);
+  GP_HIP(ctx, hipGetLastError());
+  GP_HIP(ctx, hipDeviceSynchronize());
+  GP_HIP(ctx, hipMemcpy(hC.data(), dC, hC.size() * 8, hipMemcpyDeviceToHost));
+  for (long i = 0; i < m; ++i) for (long j = 0; j < n; ++j) C[i * n + j] = hC[i * np + j];
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+  return GP_OK;
+}
+
+// device-resident timing of the GEMM core (tools/ only; not part of the public header)
+extern "C" int gp_debug_gemm_bench(int device, int ta, int tb, int m, int n, int k, int iters, double* ms_out) {
+  const char* fill_env = getenv("GP_BENCH_FILL");
+  const int fill = fill_env ? atoi(fill_env) : 0;  // 0 random, 1 zeros, 2 constant
+  using namespace gp;
+  gp_ctx* ctx = nullptr;
+  GP_HIP(ctx, hipSetDevice(device));
+  const long mp = round_up(m, TILE), np = round_up(n, TILE), kp = round_up(k, KC);
+  const long a_cols = ta ? mp : kp, b_cols = tb ? kp : np;
+  const size_t na = (size_t)mp * kp, nb = (size_t)np * kp, ncc = (size_t)mp * np;
+  std::vector<double> h(std::max(na, nb));
+  unsigned long long s = 88172645463325252ULL;
+  for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0; if (fill == 1) x = 0.0; if (fill == 2) x = 1.25; }
+  double *dA, *dB, *dC;
+  GP_HIP(ctx, hipMalloc(&dA, na * 8)); GP_HIP(ctx, hipMalloc(&dB, nb * 8)); GP_HIP(ctx, hipMalloc(&dC, ncc * 8));
+  GP_HIP(ctx, hipMemcpy(dA, h.data(), na * 8, hipMemcpyHostToDevice));
+  GP_HIP(ctx, hipMemcpy(dB, h.data(), nb * 8, hipMemcpyHostToDevice));
+  GemmP p{dA, dB, dC, a_cols, b_cols, np, 0, 0, 0, (int)kp, 1.0, 0.0, 0};
+  hipEvent_t e0, e1;
+  GP_HIP(ctx, hipEventCreate(&e0)); GP_HIP(ctx, hipEventCreate(&e1));
+  launch_gemm(nullptr, ta ? FREE_CONTIG : K_CONTIG, tb ? K_CONTIG : FREE_CONTIG, (int)mp, (int)np, 1, p);
+  GP_HIP(ctx, hipDeviceSynchronize());
+  GP_HIP(ctx, hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) launch_gemm(nullptr, ta ? FREE_CONTIG : K_CONTIG, tb ? K_CONTIG : FREE_CONTIG, (int)mp, (int)np, 1, p);
+  GP_HIP(ctx, hipEventRecord(e1));
+  GP_HIP(ctx, hipEventSynchronize(e1));
+  float ms;
+  GP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+  return GP_OK;
+}

@@ -1,0 +1,140 @@
+/*
+ * gparml_hip.h -- C ABI of the MI355X (gfx950) implementation of GParML's per-shard
+ * `partial_terms` hot path.  Plain C: opaque context, plain pointers and sizes, int status codes.
+ *
+ * The reference (markvdw/GParML) has no FFI; the hot path sits behind a Python class and a Python
+ * MapReduce backend module.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference root).  The Python host side (gparml_amd/) binds this library
+ * with ctypes and mirrors the reference's class/module surface; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - all host arrays are C-contiguous float64, owned by the caller, copied during the call;
+ *   - one context per GPU/shard; calls on one context are serialised by the caller;
+ *   - every function returns GP_OK (0) or an error code; gp_last_error(ctx) gives the message;
+ *   - alpha is the inverse squared lengthscale (ard**-2), sf2 the signal variance, beta the noise
+ *     precision -- the argument meaning of partial_terms.__init__ (partial_terms.py:16-36).
+ *
+ * One evaluation (parallel_GPLVM.py:222-279) is
+ *   gp_set_globals -> gp_phase1 -> [all-reduce gp_stats_buffer] -> gp_global_step
+ *                  -> gp_phase2 -> [all-reduce gp_grads_buffer] -> gp_finish
+ */
+#ifndef GPARML_HIP_H
+#define GPARML_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gp_ctx gp_ctx;
+
+/* status codes; the Python wrapper maps them to the exception classes the reference raises
+ * (scg_adapted.py:55 catches LinAlgError / ZeroDivisionError / ValueError / AssertionError) */
+enum {
+  GP_OK = 0,
+  GP_ERR_BAD_ARG = 1,      /* -> AssertionError / ValueError (kernel_exp.py:30-34 input assertions)        */
+  GP_ERR_NOT_PD = 2,       /* -> numpy.linalg.LinAlgError (linalg.inv / slogdet sign, partial_terms.py:459) */
+  GP_ERR_NON_FINITE = 3,   /* -> FloatingPointError (nputil.py:9 np.seterr(all='raise'))                    */
+  GP_ERR_HIP = 4,          /* -> RuntimeError                                                               */
+  GP_ERR_STATE = 5,        /* call sequence violated (e.g. phase2 before global_step) -> RuntimeError       */
+  GP_ERR_UNSUPPORTED = 6
+};
+
+/* what gp_download can fetch (every array the reference exposes on the path) */
+enum {
+  GP_ARR_KMM = 0,            /* (M,M)   partial_terms.Kmm                 partial_terms.py:94  */
+  GP_ARR_KMM_INV = 1,        /* (M,M)   partial_terms.Kmm_inv             partial_terms.py:95  */
+  GP_ARR_PSI1 = 2,           /* (N_s,M) partial_terms.exp_K_mi            partial_terms.py:49  */
+  GP_ARR_PSI2_SUM = 3,       /* (M,M)   sum_exp_K_mi_K_im                 partial_terms.py:79  */
+  GP_ARR_PSI1TY = 4,         /* (M,D)   exp_K_miY                         partial_terms.py:80  */
+  GP_ARR_KMM_PLUS_OP_INV = 5,/* (M,M)   Kmm_plus_op_inv                   partial_terms.py:82  */
+  GP_ARR_DF_DKMM = 6,        /* (M,M)   dF_dKmm()                         partial_terms.py:102 */
+  GP_ARR_DF_DPSI1TY = 7,     /* (M,D)   dF_dexp_K_miY()                   partial_terms.py:115 */
+  GP_ARR_DF_DPSI2 = 8,       /* (M,M)   dF_dexp_K_mi_K_im()               partial_terms.py:123 */
+  GP_ARR_GRAD_X_MU = 9,      /* (N_s,Q) grad_X_mu()                       partial_terms.py:367 */
+  GP_ARR_GRAD_X_S = 10,      /* (N_s,Q) grad_X_S()                        partial_terms.py:400 */
+  GP_ARR_SCALARS = 11,       /* 8 doubles: sum_YYT, sum_exp_K_ii, KL, logdet Kmm, logdet A, F, grad_beta, grad_sf2 */
+  GP_ARR_PSI2_POINTS = 12,   /* (N_s,M,M) exp_K_mi_K_im, compat only      partial_terms.py:45  */
+  GP_ARR_DKMM_DZ = 13,       /* (M,Q,M) dKmm_dZ()                         partial_terms.py:146 */
+  GP_ARR_DPSI1TY_DZ = 14,    /* (M,Q,D) dexp_K_miY_dZ()                   partial_terms.py:162 */
+  GP_ARR_DPSI2_DZ = 15,      /* (M,Q,M) dexp_K_mi_K_im_dZ()               partial_terms.py:190 */
+  GP_ARR_DKMM_DALPHA = 16,   /* (Q,M,M) dKmm_dalpha()                     partial_terms.py:247 */
+  GP_ARR_DPSI1TY_DALPHA = 17,/* (Q,M,D) dexp_K_miY_dalpha()               partial_terms.py:256 */
+  GP_ARR_DPSI2_DALPHA = 18,  /* (Q,M,M) dexp_K_mi_K_im_dalpha()           partial_terms.py:273 */
+  GP_ARR_X_MU_TRIAL = 19,    /* (N_s,Q) X_mu + step*d_mu                  local_MapReduce.py:205-211 */
+  GP_ARR_X_S_TRIAL = 20      /* (N_s,Q) softplus(X_S_raw + step*d_S)      local_MapReduce.py:214 */
+};
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* partial_terms.__init__ sizes (partial_terms.py:16-30): local shard rows N_s, outputs D, inducing M, latent Q */
+int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, int Q);
+int gp_destroy(gp_ctx* ctx);
+const char* gp_last_error(const gp_ctx* ctx);   /* ctx may be NULL: returns the last creation error */
+const char* gp_version(void);
+/* hipStream_t to launch on (NULL = default stream); lets the host order RCCL collectives with kernels */
+int gp_set_stream(gp_ctx* ctx, void* hip_stream);
+
+/* ---- data ------------------------------------------------------------------------------------ */
+/* partial_terms.set_data inputs (partial_terms.py:38-43) == what statistics_mapper loads
+ * (local_MapReduce.py:197-201).  xs_is_raw != 0: X_S is in softplus-inverse space and is transformed
+ * on the device (supporting_functions.py:153-156, local_MapReduce.py:214). */
+int gp_upload_shard(gp_ctx* ctx, const double* Y, const double* X_mu, const double* X_S, int xs_is_raw);
+/* replace only the embeddings (Y stays resident) */
+int gp_upload_embeddings(gp_ctx* ctx, const double* X_mu, const double* X_S, int xs_is_raw);
+/* search direction (2,N_s,Q) = [d_mu, d_S] of the optimiser, the .grad_d.npy of
+ * local_MapReduce.py:204-211; NULL clears it */
+int gp_set_direction(gp_ctx* ctx, const double* d);
+
+/* ---- one evaluation ------------------------------------------------------------------------- */
+/* global_statistics Z,sf2,alpha,beta (parallel_GPLVM.py:236-238), global N (options['N']) and the
+ * trial step size (options['step_size'], parallel_GPLVM.py:228) */
+int gp_set_globals(gp_ctx* ctx, const double* Z, double sf2, const double* alpha, double beta,
+                   int64_t N_global, double step_size);
+/* statistics_mapper body (local_MapReduce.py:224-240 -> partial_terms.set_data / update_local_statistics,
+ * partial_terms.py:38-52,74-87): local Psi-statistics into the packed stats buffer */
+int gp_phase1(gp_ctx* ctx);
+/* packed device buffer the host all-reduces (sum) across shards: the statistics_reducer
+ * (local_MapReduce.py:250-277).  Layout: Psi2 (Mp*Mp) | C (Mp*Dp) | sum_YYT, Psi0, KL, n_local, pad(4) */
+int gp_stats_buffer(gp_ctx* ctx, void** dev_ptr, int64_t* n_doubles);
+/* scale the reduced statistics (node drop-out rescale, local_MapReduce.py:263-264) */
+int gp_scale_stats(gp_ctx* ctx, double factor);
+/* calculate_global_statistics + Kmm parts of calculate_global_derivatives (parallel_GPLVM.py:302-369):
+ * Kmm, Cholesky of Kmm and Kmm+beta*Psi2, F, dF_d*, grad_beta.  GP_ERR_NOT_PD if a factorisation fails. */
+int gp_global_step(gp_ctx* ctx);
+/* embeddings_mapper body + data-dependent sums of the Z/alpha gradients
+ * (local_MapReduce.py:348-358; partial_terms.py:162-205, 256-284, 367-431) */
+int gp_phase2(gp_ctx* ctx, int want_embedding_grads);
+/* packed device buffer of the phase-2 sums the host all-reduces: grad_Z data part (M*Q) | grad_alpha data part (Q) */
+int gp_grads_buffer(gp_ctx* ctx, void** dev_ptr, int64_t* n_doubles);
+/* contraction into the final gradients (partial_terms.grad_Z/grad_alpha/grad_sf2/grad_beta,
+ * partial_terms.py:207-240, 286-299, 322-333, 340-360).  Any output pointer may be NULL. */
+int gp_finish(gp_ctx* ctx, double* F, double* grad_Z, double* grad_sf2, double* grad_alpha, double* grad_beta);
+
+/* ---- results ---------------------------------------------------------------------------------- */
+int gp_download(gp_ctx* ctx, int which, double* dst, int64_t n_doubles);
+/* set the reduced statistics from the host (partial_terms.set_local_statistics, partial_terms.py:54-61) */
+int gp_set_local_statistics(gp_ctx* ctx, double sum_YYT, const double* Psi2, const double* C,
+                            double sum_exp_K_ii, double KL);
+/* per-kernel device time of the last evaluation in milliseconds (HIP events on ctx's stream):
+ * out[0]=prep+generate, [1]=phase-1 contraction, [2]=global step, [3]=phase-2, [4]=total */
+int gp_last_timings(gp_ctx* ctx, double* out5);
+
+/* ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243), "next" row 8(f)-1 ------------ */
+int gp_cg_set_grads(gp_ctx* ctx);                              /* embeddings_set_grads        :29-55   */
+int gp_cg_dots(gp_ctx* ctx, double* out6);                     /* mu,kappa,theta,|g|^2,gamma  :59-140  */
+int gp_cg_max_d(gp_ctx* ctx, double alpha, double* out);       /* max |alpha*d|               :142-155 */
+int gp_cg_update(gp_ctx* ctx, int which, double a);            /* reset_d/update_d/update_X/... :160-243 */
+
+/* ---- test hooks (used by tests/ only) --------------------------------------------------------- */
+/* C = alpha*op(A)op(B) + beta*C through the library's FP64 MFMA GEMM core; A (m,k) or (k,m) if ta,
+ * B (k,n) or (n,k) if tb; any sizes (padded internally) */
+int gp_debug_gemm(int device, int ta, int tb, int m, int n, int k, double alpha, const double* A, const double* B,
+                  double beta, double* C);
+/* in-place lower Cholesky + inverse of an SPD (n,n) matrix; logdet out; returns GP_ERR_NOT_PD on failure */
+int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPARML_HIP_H */

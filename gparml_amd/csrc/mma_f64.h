@@ -139,23 +139,43 @@ __device__ __forceinline__ LaneOfs lane_offsets(int wrow0, int wcol0, int lane) 
 }
 
 template <Layout LA, Layout LB>
+__device__ __forceinline__ void load_operands(const double* sA, const double* sB, const LaneOfs& o, int k4, double (&a)[4], double (&b)[16]) {
+#pragma unroll
+  for (int ar = 0; ar < 4; ++ar)
+    a[ar] = (LA == FREE_CONTIG) ? sA[o.a[0] + 4 * k4 * LDS_RC + 16 * ar] : sA[o.a[k4] + 256 * ar];
+#pragma unroll
+  for (int bc = 0; bc < 16; ++bc)
+    b[bc] = (LB == FREE_CONTIG)
+                ? sB[o.b[0] + 4 * k4 * LDS_RC + 4 * bc]
+                : sB[o.b[k4 & 1] + (bc & 1) * 64 + ((bc >> 1) & 1) * 16 + (bc >> 2) * 256 + (((k4 >> 1) ^ (bc & 1)) << 3)];
+}
+
+__device__ __forceinline__ void mma_step(Acc& acc, const double (&a)[4], const double (&b)[16]) {
+#pragma unroll
+  for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+    for (int bc = 0; bc < 16; ++bc) mfma444_acc(acc.v[ar][bc], a[ar], b[bc]);
+}
+
+// Operand registers are double-buffered: the ds_reads of step k4+1 are issued before the 64 MFMAs of step k4,
+// so one wave alone keeps the matrix pipe busy inside a chunk.
+template <Layout LA, Layout LB>
 __device__ __forceinline__ void mma_chunk(const double* sA, const double* sB, Acc& acc, const LaneOfs& o) {
-#pragma unroll
-  for (int k4 = 0; k4 < KC / 4; ++k4) {
-    double a[4], b[16];
-#pragma unroll
-    for (int ar = 0; ar < 4; ++ar)
-      a[ar] = (LA == FREE_CONTIG) ? sA[o.a[0] + 4 * k4 * LDS_RC + 16 * ar] : sA[o.a[k4] + 256 * ar];
-#pragma unroll
-    for (int bc = 0; bc < 16; ++bc)
-      b[bc] = (LB == FREE_CONTIG)
-                  ? sB[o.b[0] + 4 * k4 * LDS_RC + 4 * bc]
-                  : sB[o.b[k4 & 1] + (bc & 1) * 64 + ((bc >> 1) & 1) * 16 + (bc >> 2) * 256 + (((k4 >> 1) ^ (bc & 1)) << 3)];
-#pragma unroll
-    for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-      for (int bc = 0; bc < 16; ++bc) mfma444_acc(acc.v[ar][bc], a[ar], b[bc]);
-  }
+  double a0[4], b0[16], a1[4], b1[16];
+  load_operands<LA, LB>(sA, sB, o, 0, a0, b0);
+  load_operands<LA, LB>(sA, sB, o, 1, a1, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_step(acc, a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_operands<LA, LB>(sA, sB, o, 2, a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_step(acc, a1, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  load_operands<LA, LB>(sA, sB, o, 3, a1, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_step(acc, a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_step(acc, a1, b1);
 }
 
 }  // namespace gp

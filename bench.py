@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: bound+gradient evaluations per second.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload at N=1: BASELINE.json configs[2]  (1 shard, N=1e6, D=100, M=512, Q=10, ARD-RBF, fixed embeddings = regime A),
+the configuration the metric is quoted on.  With N>1 every rank holds its own shard of the same size (configs[3],
+weak scaling) and the two per-evaluation reductions are RCCL all-reduces.  A step = one evaluation = phase 1 +
+all-reduce + global step + phase 2 + all-reduce + gradient read-back, inputs resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 (vector = matrix); ubench ceiling 74 (profiles/r01_ubench_f64_mfma4x4x4.txt)
+
+
+def synthetic(N, D, M, Q, seed):
+    """SURVEY.md 8(d) synthetic shard; generated with numpy on the host, outside the timed region."""
+    rs = np.random.RandomState(seed)
+    X = rs.randn(N, Q)
+    W = np.random.RandomState(1234).randn(Q, D)          # same map on every rank
+    Y = np.sin(X.dot(W)) + 0.1 * rs.randn(N, D)
+    X_mu = X + 0.05 * rs.randn(N, Q)
+    X_S = np.zeros((N, Q))
+    rz = np.random.RandomState(1)
+    Z = np.random.RandomState(0).randn(4 * M, Q)[rz.permutation(4 * M)[:M]] + 0.05 * rz.randn(M, Q)   # same Z on every rank
+    return dict(Y=Y, X_mu=X_mu, X_S=X_S, Z=Z, sf2=1.0, alpha=np.full(Q, 0.1), beta=10.0)
+
+
+def cpu_baseline(D, M, Q, N_full, budget_rows):
+    """The oracle's factorised numpy/BLAS evaluation (kind "port") on a bounded sample of the same workload."""
+    from oracle import factorised as Fz
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    d = synthetic(budget_rows, D, M, Q, seed=99)
+    Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'][:2000], d['X_mu'][:2000], d['X_S'][:2000], want_embeddings=False)
+    t = time.time()
+    Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=False, chunk=8192)
+    dt = time.time() - t
+    evals = 1.0 / (dt * N_full / budget_rows)
+    return {'value': evals, 'unit': 'evals/s', 'cores': int(threads), 'kind': 'port',
+            'sample': 'oracle/factorised.py evaluate() on %d of %d rows (D=%d M=%d Q=%d), %.1f s, scaled linearly in N'
+                      % (budget_rows, N_full, D, M, Q, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--N', type=int, default=1000000)
+    ap.add_argument('--D', type=int, default=100)
+    ap.add_argument('--M', type=int, default=512)
+    ap.add_argument('--Q', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-rows', type=int, default=200000)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    dev = torch.device('cuda', local_rank)
+
+    from gparml_amd.engine import ShardEngine
+    from gparml_amd.dist import DistributedEvaluator
+
+    d = synthetic(a.N, a.D, a.M, a.Q, seed=100 + rank)
+    eng = ShardEngine(a.N, a.D, a.M, a.Q, device=local_rank)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=a.N * world)
+    ev = DistributedEvaluator(eng, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = ev.evaluate(False)
+    barrier()
+    t0 = time.time()
+    kern = {'psi1_ms': 0.0, 'p1_kernel_ms': 0.0, 'p2_kernel_ms': 0.0, 'global_ms': 0.0, 'total_ms': 0.0}
+    for _ in range(a.steps):
+        out = ev.evaluate(False)
+        tm = eng.timings()            # HIP events on the engine's stream around each kernel of this evaluation
+        for k in kern:
+            kern[k] += tm[k]
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    for k in kern:
+        kern[k] /= a.steps
+
+    if rank == 0:
+        N, D, M, Q = a.N, a.D, a.M, a.Q
+        # algorithmic FLOPs (FMA = 2) of the dominant kernel p2_kernel: K.(2 Bbar) 2NM^2 + Y.Abar^T 2NMD + the
+        # n-contraction with [mu, mu^2, 1]: 2NM(2Q+1)   
+        flops_p2 = 2.0 * N * M * (M + D) + 2.0 * N * M * (2 * Q + 1)
+        ach = flops_p2 / (kern['p2_kernel_ms'] * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get('p2_kernel_hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        W_eval = float(N) * M * (3.0 * M + 4.0 * D + 12.0 * Q)      # SURVEY.md 8(d) regime-A figure for a whole evaluation
+        res = {
+            'metric': 'variational bound+grad evals/sec', 'value': world * a.steps / dt, 'unit': 'evals/s (one eval = one %d-point shard)' % N,
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[%d]: %d shard(s) x N=%d, D=%d, M=%d, Q=%d, ARD-RBF sparse GP (fixed embeddings)'
+                                   % (2 if world == 1 else 3, world, N, D, M, Q),
+                       'N_per_gpu': N, 'D': D, 'M': M, 'Q': Q, 'regime': 'A', 'parallelism': 'dp%d' % world,
+                       'points_per_sec': world * N * a.steps / dt, 'F': out['F'],
+                       'device_ms': {k: round(v, 4) for k, v in kern.items()},
+                       'eval_flops_survey_8d': W_eval, 'eval_fraction_of_fp64_peak': W_eval / (kern['total_ms'] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+            'roofline': {'bound': 'mfma', 'kernel': 'gp::p2_kernel', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / FP64_PEAK_TFLOPS, 'traffic': traffic},
+        }
+        if not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(D, M, Q, N, min(a.cpu_rows, N))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,92 @@
+"""ctypes binding of libgparml_hip.so (C ABI: include/gparml_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgparml_hip.so')
+
+GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_ERR_HIP, GP_ERR_STATE, GP_ERR_UNSUPPORTED = range(7)
+
+# gp_download selectors (include/gparml_hip.h)
+ARR = dict(KMM=0, KMM_INV=1, PSI1=2, PSI2_SUM=3, PSI1TY=4, KMM_PLUS_OP_INV=5, DF_DKMM=6, DF_DPSI1TY=7, DF_DPSI2=8,
+           GRAD_X_MU=9, GRAD_X_S=10, SCALARS=11, PSI2_POINTS=12, DKMM_DZ=13, DPSI1TY_DZ=14, DPSI2_DZ=15, DKMM_DALPHA=16,
+           DPSI1TY_DALPHA=17, DPSI2_DALPHA=18, X_MU_TRIAL=19, X_S_TRIAL=20)
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+
+# every symbol include/gparml_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'gp_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'gp_destroy': (ctypes.c_int, [_vp]),
+    'gp_last_error': (ctypes.c_char_p, [_vp]),
+    'gp_version': (ctypes.c_char_p, []),
+    'gp_set_stream': (ctypes.c_int, [_vp, _vp]),
+    'gp_upload_shard': (ctypes.c_int, [_vp, _dp, _dp, _dp, ctypes.c_int]),
+    'gp_upload_embeddings': (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),
+    'gp_set_direction': (ctypes.c_int, [_vp, _dp]),
+    'gp_set_globals': (ctypes.c_int, [_vp, _dp, ctypes.c_double, _dp, ctypes.c_double, _i64, ctypes.c_double]),
+    'gp_phase1': (ctypes.c_int, [_vp]),
+    'gp_stats_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    'gp_scale_stats': (ctypes.c_int, [_vp, ctypes.c_double]),
+    'gp_global_step': (ctypes.c_int, [_vp]),
+    'gp_phase2': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'gp_grads_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    'gp_finish': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
+    'gp_download': (ctypes.c_int, [_vp, ctypes.c_int, _dp, _i64]),
+    'gp_set_local_statistics': (ctypes.c_int, [_vp, ctypes.c_double, _dp, _dp, ctypes.c_double, ctypes.c_double]),
+    'gp_last_timings': (ctypes.c_int, [_vp, _dp]),
+    'gp_cg_set_grads': (ctypes.c_int, [_vp]),
+    'gp_cg_dots': (ctypes.c_int, [_vp, _dp]),
+    'gp_cg_max_d': (ctypes.c_int, [_vp, ctypes.c_double, _dp]),
+    'gp_cg_update': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
+    'gp_debug_gemm': (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_double, _dp, _dp, ctypes.c_double, _dp]),
+    'gp_debug_potrf_inverse': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
+}
+
+_lib = None
+
+
+class GparmlHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises ImportError with build instructions if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('gparml_amd: %s is missing -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def as_c(a):
+    """C-contiguous float64 view/copy + its ctypes pointer."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def raise_for(rc, lib, ctx, what):
+    """Map status codes to the exception classes the reference raises (scg_adapted.py:55)."""
+    if rc == GP_OK:
+        return
+    msg = lib.gp_last_error(ctx)
+    msg = '%s: %s' % (what, msg.decode() if msg else 'error %d' % rc)
+    if rc == GP_ERR_BAD_ARG:
+        raise AssertionError(msg)
+    if rc == GP_ERR_NOT_PD:
+        raise np.linalg.LinAlgError(msg)
+    if rc == GP_ERR_NON_FINITE:
+        raise FloatingPointError(msg)
+    raise GparmlHipError(msg)

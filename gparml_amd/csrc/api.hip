@@ -1,5 +1,8 @@
 // extern "C" entry points of libgparml_hip.so (see include/gparml_hip.h).
 #include "gp_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 
 namespace gp {
 thread_local std::string g_create_error;
@@ -13,7 +16,425 @@ int fail(gp_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) ctx->err = buf; else g_create_error = buf;
   return code;
 }
+
+template <typename T>
+static int dalloc(gp_ctx* c, T** p, size_t count) {
+  GP_HIP(c, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+  GP_HIP(c, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
+  return GP_OK;
+}
+#define GP_TRY(x) do { int rc__ = (x); if (rc__ != GP_OK) return rc__; } while (0)
+
+__global__ void sumsq_kernel(const double* __restrict__ x, long n, double* part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) s += x[i] * x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// gather a padded device matrix [rows_p][ld] into a dense host-shaped [rows][cols] staging buffer
+__global__ void gather2d_kernel(const double* __restrict__ src, long ld, long rows, long cols, double* __restrict__ dst) {
+  const long total = rows * cols;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long r = i / cols, c = i - r * cols;
+    dst[i] = src[r * ld + c];
+  }
+}
+__global__ void scatter2d_kernel(const double* __restrict__ src, long rows, long cols, double* __restrict__ dst, long ld, long rows_p, long cols_p) {
+  const long total = rows_p * cols_p;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long r = i / cols_p, c = i - r * cols_p;
+    dst[r * ld + c] = (r < rows && c < cols) ? src[r * cols + c] : 0.0;
+  }
+}
+__global__ void scale_kernel(double* x, long n, double f) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] *= f;
+}
+// Zaug[m] = [1, z_m, z_m^2] (rows >= M zero), Z padded copy
+__global__ void zaug_kernel(const double* __restrict__ Zin, int M, int Mp, int Q, int CZp, double* __restrict__ Z, double* __restrict__ Zaug) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= Mp) return;
+  for (int c = 0; c < CZp; ++c) Zaug[(long)m * CZp + c] = 0.0;
+  for (int q = 0; q < Q; ++q) {
+    const double z = (m < M) ? Zin[(long)m * Q + q] : 0.0;
+    Z[(long)m * Q + q] = z;
+    if (m < M) { Zaug[(long)m * CZp + 1 + q] = z; Zaug[(long)m * CZp + 1 + Q + q] = z * z; }
+  }
+  if (m < M) Zaug[(long)m * CZp] = 1.0;
+}
+
+static int blocks_for(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 8192)); }
+
+static int download_matrix(gp_ctx* c, const double* src, long ld, long rows, long cols, double* dst, int64_t n) {
+  if (n != rows * cols) return fail(c, GP_ERR_BAD_ARG, "gp_download: expected %ld doubles, got %ld", rows * cols, (long)n);
+  double* tmp = nullptr;
+  GP_HIP(c, hipMalloc((void**)&tmp, std::max<long>(rows * cols, 1) * 8));
+  hipLaunchKernelGGL(gather2d_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, c->stream, src, ld, rows, cols, tmp);
+  hipError_t e = hipMemcpyAsync(dst, tmp, rows * cols * 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(c, GP_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+  return GP_OK;
+}
 }  // namespace gp
 
+using namespace gp;
+
 extern "C" const char* gp_last_error(const gp_ctx* ctx) { return ctx ? ctx->err.c_str() : gp::g_create_error.c_str(); }
-extern "C" const char* gp_version(void) { return "gparml_hip 0.1 (gfx950)"; }
+extern "C" const char* gp_version(void) { return "gparml_hip 0.1 (gfx950, fp64 4x4x4-mfma)"; }
+
+extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, int Q) {
+  if (!out) return fail(nullptr, GP_ERR_BAD_ARG, "gp_create: out is NULL");
+  *out = nullptr;
+  if (N_s <= 0 || D <= 0 || M <= 0 || Q <= 0) return fail(nullptr, GP_ERR_BAD_ARG, "gp_create: N_s, D, M, Q must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, GP_ERR_HIP, "gp_create: no HIP device available");
+  if (device < 0 || device >= ndev) return fail(nullptr, GP_ERR_BAD_ARG, "gp_create: device %d out of range (%d devices)", device, ndev);
+  gp_ctx* c = new gp_ctx();
+  c->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { delete c; return fail(nullptr, GP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e)); }
+  c->N = N_s; c->D = D; c->M = M; c->Q = Q;
+  c->Np = round_up(N_s, TILE);
+  c->Mp = (int)round_up(M, TILE);
+  c->Dp = (int)round_up(D, TILE);
+  c->LDK = c->Mp + c->Dp;
+  c->CX = 2 * Q + 1; c->CXp = (int)round_up(c->CX, 4);
+  c->CZ = 2 * Q + 1; c->CZp = (int)round_up(c->CZ, 4);
+  const long Mp = c->Mp, Dp = c->Dp, Np = c->Np;
+  int rc = GP_OK;
+  auto A = [&](auto** p, size_t n) { if (rc == GP_OK) rc = dalloc(c, p, n); };
+  A(&c->Kaug, (size_t)Np * c->LDK);
+  A(&c->Xmu, (size_t)N_s * Q); A(&c->Xs, (size_t)N_s * Q); A(&c->dir, (size_t)2 * N_s * Q);
+  A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
+  A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp);
+  A(&c->stats, (size_t)Mp * Mp + Mp * Dp + SC_COUNT);
+  A(&c->grads, (size_t)M * Q + Q);
+  // phase-1 tile table: Psi2 upper tiles first, then the C tiles
+  std::vector<int> tiles;
+  const int mt = c->Mp / TILE, dt = c->Dp / TILE;
+  for (int i = 0; i < mt; ++i) for (int j = i; j < mt; ++j) { tiles.push_back(i); tiles.push_back(j); }
+  for (int i = 0; i < mt; ++i) for (int j = 0; j < dt; ++j) { tiles.push_back(i); tiles.push_back(mt + j); }
+  c->n_tiles = (int)tiles.size() / 2;
+  A(&c->tiles, tiles.size());
+  if (rc == GP_OK && hipMemcpy(c->tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, GP_ERR_HIP, "tile table upload failed");
+  const int total_chunks = (int)(Np / KC);
+  const int S = std::max(1, std::min(512 / std::max(1, std::min(c->n_tiles, mt * dt > 0 ? c->n_tiles : 1)), total_chunks));
+  // worst case slices x tiles (regime B uses fewer tiles, hence possibly more slices)
+  const int Tb = mt * dt;
+  const int Sb = std::max(1, std::min(512 / std::max(1, Tb), total_chunks));
+  c->part_doubles = (size_t)std::max((long)(S + 8) * c->n_tiles, (long)(Sb + 8) * Tb) * TILE * TILE;
+  A(&c->part, c->part_doubles);
+  c->kl_blocks = blocks_for(Np);
+  A(&c->klpart, (size_t)c->kl_blocks + 8192);
+  A(&c->Kmm, (size_t)2 * Mp * Mp); A(&c->Lmat, (size_t)2 * Mp * Mp); A(&c->Linv, (size_t)2 * Mp * Mp); A(&c->Inv, (size_t)2 * Mp * Mp);
+  A(&c->KmmKeep, (size_t)Mp * Mp); A(&c->T1, (size_t)Mp * std::max<long>(std::max(Mp, Dp), 256)); A(&c->T2, (size_t)Mp * std::max(Mp, Dp));
+  A(&c->dFdK, (size_t)Mp * Mp); A(&c->Bbar, (size_t)Mp * Mp);
+  A(&c->E, (size_t)Mp * Dp); A(&c->PsiE, (size_t)Mp * Dp); A(&c->Abar, (size_t)Mp * Dp);
+  A(&c->Bm, (size_t)c->LDK * Mp);
+  A(&c->gs, (size_t)GS_COUNT + 8); A(&c->gK, (size_t)M * Q + Q);
+  // phase 2
+  c->p2_slices = std::max(1, std::min<int>(512 / mt, (int)(Np / TILE)));
+  A(&c->Rpart, (size_t)2 * (c->p2_slices + 8) * Mp * c->CXp);
+  A(&c->HZp, (size_t)(Mp / WT) * Np * c->CZp);
+  A(&c->gXmu, (size_t)N_s * Q); A(&c->gXs, (size_t)N_s * Q);
+  c->ga_blocks = blocks_for(Np);
+  A(&c->gapart, (size_t)c->ga_blocks * Q);
+  A(&c->g_latest, (size_t)2 * N_s * Q); A(&c->g_new, (size_t)2 * N_s * Q); A(&c->g_old, (size_t)2 * N_s * Q);
+  for (int i = 0; i < 14 && rc == GP_OK; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) rc = fail(c, GP_ERR_HIP, "hipEventCreate failed");
+  if (rc == GP_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(c, GP_ERR_HIP, "device sync failed after allocation");
+  if (rc != GP_OK) { gp::g_create_error = c->err; gp_destroy(c); return rc; }
+  *out = c;
+  return GP_OK;
+}
+
+extern "C" int gp_destroy(gp_ctx* c) {
+  if (!c) return GP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
+                    c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
+                    c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
+                    c->HZp, c->gXmu, c->gXs, c->gapart, c->g_latest, c->g_new, c->g_old};
+  for (double* b : bufs) if (b) (void)hipFree(b);
+  if (c->tiles) (void)hipFree(c->tiles);
+  for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  delete c;
+  return GP_OK;
+}
+
+extern "C" int gp_set_stream(gp_ctx* c, void* s) {
+  if (!c) return GP_ERR_BAD_ARG;
+  c->stream = (hipStream_t)s;
+  return GP_OK;
+}
+
+static int upload_embeddings(gp_ctx* c, const double* X_mu, const double* X_S, int xs_is_raw) {
+  const size_t nq = (size_t)c->N * c->Q;
+  bool all_zero = true, any_neg = false, finite = true;
+  for (size_t i = 0; i < nq; ++i) {
+    const double s = X_S[i];
+    if (s != 0.0) all_zero = false;
+    if (s < 0.0) any_neg = true;
+    if (!std::isfinite(s) || !std::isfinite(X_mu[i])) finite = false;
+  }
+  if (!finite) return fail(c, GP_ERR_NON_FINITE, "embeddings contain non-finite values");
+  if (!xs_is_raw && any_neg) return fail(c, GP_ERR_BAD_ARG, "X_S must be >= 0 (kernel_exp.py:30 assertion)");
+  if (!xs_is_raw && !all_zero) {
+    for (size_t i = 0; i < nq; ++i) if (X_S[i] == 0.0) return fail(c, GP_ERR_NON_FINITE, "X_S mixes zero and non-zero variances: log(0) in the KL term (partial_terms.py:85)");
+  }
+  c->xs_raw = xs_is_raw != 0;
+  c->regime_A = (!xs_is_raw) && all_zero;
+  GP_HIP(c, hipMemcpyAsync(c->Xmu, X_mu, nq * 8, hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipMemcpyAsync(c->Xs, X_S, nq * 8, hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  c->state = 0;
+  return GP_OK;
+}
+
+extern "C" int gp_upload_shard(gp_ctx* c, const double* Y, const double* X_mu, const double* X_S, int xs_is_raw) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (!Y || !X_mu || !X_S) return fail(c, GP_ERR_BAD_ARG, "gp_upload_shard: NULL array");
+  GP_HIP(c, hipSetDevice(c->device));
+  const size_t nd = (size_t)c->N * c->D;
+  double* dY = nullptr;
+  GP_HIP(c, hipMalloc((void**)&dY, nd * 8));
+  hipError_t e = hipMemcpyAsync(dY, Y, nd * 8, hipMemcpyHostToDevice, c->stream);
+  int rc = GP_OK;
+  if (e != hipSuccess) rc = fail(c, GP_ERR_HIP, "Y upload failed: %s", hipGetErrorString(e));
+  if (rc == GP_OK) rc = run_upload_y(c, dY);
+  if (rc == GP_OK) {
+    // sum_YYT (partial_terms.py:40) once per upload
+    const int nb = 1024;
+    double* part = c->klpart + c->kl_blocks;  // spare tail of the KL partial buffer (8192 doubles)
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, c->stream, dY, (long)nd, part);
+    std::vector<double> h(nb);
+    e = hipMemcpyAsync(h.data(), part, nb * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, GP_ERR_HIP, "sum_YYT failed: %s", hipGetErrorString(e));
+    double s = 0.0;
+    for (double v : h) s += v;
+    c->sumYY = s;
+    if (!std::isfinite(s)) rc = fail(c, GP_ERR_NON_FINITE, "Y contains non-finite values");
+  }
+  (void)hipFree(dY);
+  if (rc != GP_OK) return rc;
+  GP_TRY(upload_embeddings(c, X_mu, X_S, xs_is_raw));
+  c->have_data = true;
+  c->have_dir = false;
+  return GP_OK;
+}
+
+extern "C" int gp_upload_embeddings(gp_ctx* c, const double* X_mu, const double* X_S, int xs_is_raw) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (!c->have_data) return fail(c, GP_ERR_STATE, "gp_upload_embeddings before gp_upload_shard");
+  if (!X_mu || !X_S) return fail(c, GP_ERR_BAD_ARG, "gp_upload_embeddings: NULL array");
+  GP_HIP(c, hipSetDevice(c->device));
+  return upload_embeddings(c, X_mu, X_S, xs_is_raw);
+}
+
+extern "C" int gp_set_direction(gp_ctx* c, const double* d) {
+  if (!c) return GP_ERR_BAD_ARG;
+  GP_HIP(c, hipSetDevice(c->device));
+  if (!d) { c->have_dir = false; return GP_OK; }
+  GP_HIP(c, hipMemcpyAsync(c->dir, d, (size_t)2 * c->N * c->Q * 8, hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  c->have_dir = true;
+  c->state = 0;
+  return GP_OK;
+}
+
+extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const double* alpha, double beta, int64_t N_global, double step) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (!Z || !alpha) return fail(c, GP_ERR_BAD_ARG, "gp_set_globals: NULL array");
+  if (!(sf2 > 0.0)) return fail(c, GP_ERR_BAD_ARG, "sf2 must be > 0 (kernels.py:62 assert sf > 0)");
+  if (!(beta > 0.0) || !std::isfinite(beta)) return fail(c, GP_ERR_BAD_ARG, "beta must be finite and > 0");
+  for (int q = 0; q < c->Q; ++q) {
+    if (!(alpha[q] >= 0.0)) return fail(c, GP_ERR_BAD_ARG, "alpha must be >= 0 (kernel_exp.py:31 assertion)");
+    if (!std::isfinite(alpha[q])) return fail(c, GP_ERR_NON_FINITE, "alpha is not finite");
+  }
+  for (long i = 0; i < (long)c->M * c->Q; ++i) if (!std::isfinite(Z[i])) return fail(c, GP_ERR_NON_FINITE, "Z is not finite");
+  if (N_global < c->N) return fail(c, GP_ERR_BAD_ARG, "N_global (%ld) smaller than the local shard (%ld)", (long)N_global, (long)c->N);
+  GP_HIP(c, hipSetDevice(c->device));
+  double* tmp = c->T1;  // scratch for the unpadded Z
+  GP_HIP(c, hipMemcpyAsync(tmp, Z, (size_t)c->M * c->Q * 8, hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipMemcpyAsync(c->alpha, alpha, (size_t)c->Q * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(zaug_kernel, dim3((c->Mp + 255) / 256), dim3(256), 0, c->stream, tmp, c->M, c->Mp, c->Q, c->CZp, c->Z, c->Zaug);
+  GP_HIP(c, hipGetLastError());
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  c->sf2 = sf2; c->beta = beta; c->N_global = N_global; c->step = step;
+  c->have_globals = true;
+  c->state = 0;
+  return GP_OK;
+}
+
+extern "C" int gp_phase1(gp_ctx* c) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (!c->have_data || !c->have_globals) return fail(c, GP_ERR_STATE, "gp_phase1 needs gp_upload_shard and gp_set_globals first");
+  GP_HIP(c, hipSetDevice(c->device));
+  GP_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  GP_TRY(run_prep_and_generate(c));
+  GP_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  GP_TRY(run_phase1(c));
+  GP_HIP(c, hipEventRecord(c->ev[2], c->stream));
+  c->state = 1;
+  return GP_OK;
+}
+
+extern "C" int gp_stats_buffer(gp_ctx* c, void** dev_ptr, int64_t* n) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (dev_ptr) *dev_ptr = c->stats;
+  if (n) *n = (int64_t)c->Mp * c->Mp + (int64_t)c->Mp * c->Dp + SC_COUNT;
+  return GP_OK;
+}
+
+extern "C" int gp_grads_buffer(gp_ctx* c, void** dev_ptr, int64_t* n) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (dev_ptr) *dev_ptr = c->grads;
+  if (n) *n = (int64_t)c->M * c->Q + c->Q;
+  return GP_OK;
+}
+
+extern "C" int gp_scale_stats(gp_ctx* c, double f) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (c->state < 1) return fail(c, GP_ERR_STATE, "gp_scale_stats before gp_phase1");
+  GP_HIP(c, hipSetDevice(c->device));
+  const long n = (long)c->Mp * c->Mp + (long)c->Mp * c->Dp + SC_COUNT;
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->stats, n, f);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+extern "C" int gp_global_step(gp_ctx* c) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (c->state < 1) return fail(c, GP_ERR_STATE, "gp_global_step before gp_phase1 / gp_set_local_statistics");
+  GP_HIP(c, hipSetDevice(c->device));
+  GP_HIP(c, hipEventRecord(c->ev[3], c->stream));
+  const int rc_gs = run_global_step(c);
+  GP_HIP(c, hipEventRecord(c->ev[4], c->stream));
+  if (rc_gs != GP_OK) return rc_gs;
+  c->state = 2;
+  return GP_OK;
+}
+
+extern "C" int gp_phase2(gp_ctx* c, int want_embedding_grads) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_phase2 before gp_global_step");
+  if (!c->have_data) return fail(c, GP_ERR_STATE, "gp_phase2 without shard data");
+  GP_HIP(c, hipSetDevice(c->device));
+  GP_HIP(c, hipEventRecord(c->ev[5], c->stream));
+  if ((want_embedding_grads != 0) != c->want_emb) {
+    // the per-point feature matrix depends on the mode: rebuild the trial point
+    c->want_emb = want_embedding_grads != 0;
+    GP_TRY(run_prep_and_generate(c));
+  }
+  GP_TRY(run_phase2(c));
+  GP_HIP(c, hipEventRecord(c->ev[6], c->stream));
+  c->state = 3;
+  return GP_OK;
+}
+
+extern "C" int gp_last_timings(gp_ctx* c, double* out8) {
+  double* out5 = out8;
+  if (!c || !out8) return GP_ERR_BAD_ARG;
+  GP_HIP(c, hipSetDevice(c->device));
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 8; ++i) out8[i] = 0.0;
+  float ms;
+  if (c->state >= 1 && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) out5[0] = ms;
+  if (c->state >= 1 && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) out5[1] = ms;
+  if (c->state >= 2 && hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) out5[2] = ms;
+  if (c->state >= 3 && hipEventElapsedTime(&ms, c->ev[5], c->ev[6]) == hipSuccess) out5[3] = ms;
+  out5[4] = out5[0] + out5[1] + out5[2] + out5[3];
+  if (c->state >= 1 && hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) out8[5] = ms;
+  if (c->state >= 1 && hipEventElapsedTime(&ms, c->ev[10], c->ev[11]) == hipSuccess) out8[6] = ms;
+  if (c->state >= 3 && hipEventElapsedTime(&ms, c->ev[12], c->ev[13]) == hipSuccess) out8[7] = ms;
+  return GP_OK;
+}
+
+extern "C" int gp_download(gp_ctx* c, int which, double* dst, int64_t n) {
+  if (!c || !dst) return GP_ERR_BAD_ARG;
+  GP_HIP(c, hipSetDevice(c->device));
+  const long M = c->M, Mp = c->Mp, D = c->D, Dp = c->Dp, N = c->N, Q = c->Q;
+  switch (which) {
+    case GP_ARR_PSI1: return download_matrix(c, c->Kaug, c->LDK, N, M, dst, n);
+    case GP_ARR_PSI2_SUM: return download_matrix(c, c->stats, Mp, M, M, dst, n);
+    case GP_ARR_PSI1TY: return download_matrix(c, c->stats + Mp * Mp, Dp, M, D, dst, n);
+    case GP_ARR_KMM: return download_matrix(c, c->KmmKeep, Mp, M, M, dst, n);
+    case GP_ARR_KMM_INV: return download_matrix(c, c->Inv, Mp, M, M, dst, n);
+    case GP_ARR_KMM_PLUS_OP_INV: return download_matrix(c, c->Inv + Mp * Mp, Mp, M, M, dst, n);
+    case GP_ARR_DF_DKMM: return download_matrix(c, c->dFdK, Mp, M, M, dst, n);
+    case GP_ARR_DF_DPSI1TY: return download_matrix(c, c->Abar, Dp, M, D, dst, n);
+    case GP_ARR_DF_DPSI2: return download_matrix(c, c->Bbar, Mp, M, M, dst, n);
+    case GP_ARR_GRAD_X_MU: return download_matrix(c, c->gXmu, Q, N, Q, dst, n);
+    case GP_ARR_GRAD_X_S: return download_matrix(c, c->gXs, Q, N, Q, dst, n);
+    case GP_ARR_X_MU_TRIAL: return download_matrix(c, c->mu, Q, N, Q, dst, n);
+    case GP_ARR_X_S_TRIAL: return download_matrix(c, c->S, Q, N, Q, dst, n);
+    case GP_ARR_SCALARS: {
+      if (n != 8) return fail(c, GP_ERR_BAD_ARG, "GP_ARR_SCALARS wants 8 doubles");
+      double sc[SC_COUNT];
+      GP_HIP(c, hipMemcpyAsync(sc, c->stats + Mp * Mp + Mp * Dp, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
+      GP_HIP(c, hipStreamSynchronize(c->stream));
+      dst[0] = sc[SC_SUM_YYT]; dst[1] = sc[SC_PSI0]; dst[2] = sc[SC_KL];
+      dst[3] = c->h_gs[GS_LOGDET_K]; dst[4] = c->h_gs[GS_LOGDET_A]; dst[5] = c->h_gs[GS_F]; dst[6] = c->h_gs[GS_GRAD_BETA]; dst[7] = c->h_gs[GS_GRAD_SF2];
+      return GP_OK;
+    }
+    default: return fail(c, GP_ERR_UNSUPPORTED, "gp_download: array %d not available", which);
+  }
+}
+
+extern "C" int gp_set_local_statistics(gp_ctx* c, double sum_YYT, const double* Psi2, const double* C, double sum_exp_K_ii, double KL) {
+  if (!c || !Psi2 || !C) return GP_ERR_BAD_ARG;
+  if (!c->have_globals) return fail(c, GP_ERR_STATE, "gp_set_local_statistics before gp_set_globals");
+  GP_HIP(c, hipSetDevice(c->device));
+  const long M = c->M, Mp = c->Mp, D = c->D, Dp = c->Dp;
+  double* tmp = c->T2;
+  GP_HIP(c, hipMemcpyAsync(tmp, Psi2, M * M * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(scatter2d_kernel, dim3(blocks_for(Mp * Mp)), dim3(256), 0, c->stream, tmp, M, M, c->stats, Mp, Mp, Mp);
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  GP_HIP(c, hipMemcpyAsync(tmp, C, M * D * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(scatter2d_kernel, dim3(blocks_for(Mp * Dp)), dim3(256), 0, c->stream, tmp, M, D, c->stats + Mp * Mp, Dp, Mp, Dp);
+  double sc[SC_COUNT] = {0};
+  sc[SC_SUM_YYT] = sum_YYT; sc[SC_PSI0] = sum_exp_K_ii; sc[SC_KL] = KL; sc[SC_NLOCAL] = sum_exp_K_ii / c->sf2;
+  GP_HIP(c, hipMemcpyAsync(c->stats + Mp * Mp + Mp * Dp, sc, sizeof(sc), hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->state < 1) c->state = 1;
+  return GP_OK;
+}
+
+// ---- not built yet -------------------------------------------------------------------------------------------------
+// final = Kmm parts (global step) + all-reduced data parts (phase 2)
+__global__ void add_kernel(const double* a, const double* b, double* out, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = a[i] + b[i];
+}
+
+extern "C" int gp_finish(gp_ctx* c, double* F, double* grad_Z, double* grad_sf2, double* grad_alpha, double* grad_beta) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_finish before gp_global_step");
+  GP_HIP(c, hipSetDevice(c->device));
+  if (F) *F = c->h_gs[GS_F];
+  if (grad_sf2) *grad_sf2 = c->h_gs[GS_GRAD_SF2];
+  if (grad_beta) *grad_beta = c->h_gs[GS_GRAD_BETA];
+  if (grad_Z || grad_alpha) {
+    if (c->state < 3) return fail(c, GP_ERR_STATE, "gp_finish: gradients requested before gp_phase2");
+    const long n = (long)c->M * c->Q + c->Q;
+    double* tmp = c->T2;
+    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->gK, c->grads, tmp, n);
+    std::vector<double> h(n);
+    GP_HIP(c, hipMemcpyAsync(h.data(), tmp, n * 8, hipMemcpyDeviceToHost, c->stream));
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+    if (grad_Z) memcpy(grad_Z, h.data(), (size_t)c->M * c->Q * 8);
+    if (grad_alpha) memcpy(grad_alpha, h.data() + (size_t)c->M * c->Q, (size_t)c->Q * 8);
+  }
+  return GP_OK;
+}
+extern "C" int gp_cg_set_grads(gp_ctx* c) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }
+extern "C" int gp_cg_dots(gp_ctx* c, double*) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }
+extern "C" int gp_cg_max_d(gp_ctx* c, double, double*) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }
+extern "C" int gp_cg_update(gp_ctx* c, int, double) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }

@@ -15,9 +15,10 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow0 = (wave >> 1) * WT, wcol0 = (wave & 1) * WT;
-  const double* A = p.A + (long)bz * p.sA;
-  const double* B = p.B + (long)bz * p.sB;
-  double* C = p.C + (long)bz * p.sC;
+  const int bi = bz % p.inner, bo = bz / p.inner;
+  const double* A = p.A + (long)bi * p.sA + (long)bo * p.oA;
+  const double* B = p.B + (long)bi * p.sB + (long)bo * p.oB;
+  double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
   const long row0 = (long)by * TILE, col0 = (long)bx * TILE;
   const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda : A + row0;
   const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb : B + col0;

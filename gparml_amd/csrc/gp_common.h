@@ -19,13 +19,21 @@ struct GemmP {
   const double* B;
   double* C;
   long lda, ldb, ldc;
-  long sA, sB, sC;  // batch strides (doubles)
+  long sA, sB, sC;  // batch strides (doubles) of the inner batch index
   int K;            // multiple of KC
   double alpha, beta;
   int tri;          // 0 all tiles, 1 only tiles with row-tile >= col-tile (lower), 2 only upper
+  int inner = 1 << 30;  // blockIdx.z = i + inner * o: inner index i uses sA/sB/sC, outer index o uses oA/oB/oC
+  long oA = 0, oB = 0, oC = 0;
 };
 // m, n multiples of TILE; la/lb: Layout of A (free index = rows of C) and B (free index = cols of C)
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p);
+
+// index of the scalars at the tail of the packed statistics buffer
+enum { SC_SUM_YYT = 0, SC_PSI0 = 1, SC_KL = 2, SC_NLOCAL = 3, SC_COUNT = 8 };
+// device scalars produced by the global step (GP_ARR_SCALARS order after the first three)
+enum { GS_LOGDET_K = 0, GS_LOGDET_A = 1, GS_F = 2, GS_GRAD_BETA = 3, GS_GRAD_SF2 = 4, GS_FAIL = 5, GS_TR_KIPSI2 = 6, GS_TR_PPSI2 = 7,
+       GS_TR_CE = 8, GS_TR_EPSI2E = 9, GS_SUM_V = 10, GS_SUM_AC = 11, GS_SUM_BPSI2 = 12, GS_COUNT = 16 };
 
 }  // namespace gp
 
@@ -34,20 +42,90 @@ struct gp_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   // sizes
-  int64_t N = 0;      // local shard rows
-  int64_t Np = 0;     // padded to TILE
+  int64_t N = 0;   // local shard rows
+  int64_t Np = 0;  // padded to TILE
   int D = 0, M = 0, Q = 0;
-  int Mp = 0, Dp = 0, LDK = 0;
+  int Mp = 0, Dp = 0, LDK = 0;  // padded M, D (multiples of TILE) and the row stride of Kaug = Mp + Dp
+  int CX = 0, CXp = 0;          // per-point feature columns [f1(Q), f2(Q), 1], padded to 4
+  int CZ = 0, CZp = 0;          // inducing feature columns [1, Z(Q), Z^2(Q)], padded to 4
   int64_t N_global = 0;
   double sf2 = 1, beta = 1, step = 0;
-  bool regime_A = true;
-  bool xs_raw = false;
-  int state = 0;      // 0 created, 1 data, 2 globals, 3 phase1, 4 global step, 5 phase2
+  bool regime_A = true;   // every variance exactly zero (fixed embeddings)
+  bool xs_raw = false;    // X_S stored in softplus-inverse space
+  bool have_data = false, have_globals = false, have_dir = false;
+  int state = 0;          // 0 nothing, 1 phase1 done, 2 stats final (global step done), 3 phase2 done
+  bool want_emb = false;
+
+  // ---- device buffers ----
+  double* Kaug = nullptr;     // [Np][LDK]  Psi1 | Y
+  double* Xmu = nullptr;      // [N][Q] base means
+  double* Xs = nullptr;       // [N][Q] base variances (raw or actual)
+  double* dir = nullptr;      // [2][N][Q] search direction
+  double* mu = nullptr;       // [Np][Q] trial means
+  double* S = nullptr;        // [Np][Q] trial variances (actual)
+  double* lnc1 = nullptr;     // [Np] ln(sf2) - 1/2 sum ln(a S + 1)
+  double* Xa = nullptr;       // [Np][CXp] per-point features for the n-contraction
+  double* Z = nullptr;        // [Mp][Q] (rows >= M zero)
+  double* alpha = nullptr;    // [Q]
+  double* Zaug = nullptr;     // [Mp][CZp]
+  double* stats = nullptr;    // packed: Psi2 [Mp*Mp] | C [Mp*Dp] | scalars [SC_COUNT]
+  bool stats_external = false;
+  double* grads = nullptr;    // packed: gZ_data [M*Q] | galpha_data [Q]
+  bool grads_external = false;
+  double* part = nullptr;     // phase-1 split-k partials
+  size_t part_doubles = 0;
+  int* tiles = nullptr;       // phase-1 tile table (int2)
+  int n_tiles = 0, p1_slices = 0, p1_cps = 0;
+  double* klpart = nullptr;   // [blocks] partial KL sums
+  int kl_blocks = 0;
+  double sumYY = 0;           // host copy, computed at upload
+  // global step
+  double* Kmm = nullptr;      // batch of 2: [Kmm ; A] -> factorised in place into [Lk ; La]
+  double* Lmat = nullptr;     // [2][Mp][Mp] Cholesky factors
+  double* Linv = nullptr;     // [2][Mp][Mp] inverse factors
+  double* Inv = nullptr;      // [2][Mp][Mp] Ki, P
+  double* KmmKeep = nullptr;  // [Mp][Mp] Kmm (kept for downloads / derivative parts)
+  double* T1 = nullptr;       // [Mp][Mp] scratch
+  double* T2 = nullptr;       // [Mp][Mp] scratch
+  double* dFdK = nullptr;     // [Mp][Mp]
+  double* Bbar = nullptr;     // [Mp][Mp]
+  double* E = nullptr;        // [Mp][Dp]
+  double* PsiE = nullptr;     // [Mp][Dp]
+  double* Abar = nullptr;     // [Mp][Dp]
+  double* Bm = nullptr;       // [LDK][Mp] = [2 Bbar ; Abar^T]
+  double* gs = nullptr;       // [GS_COUNT] device scalars
+  double* gK = nullptr;       // [M*Q + Q] Kmm-parts of grad_Z / grad_alpha (+ regime-B alpha term)
+  double h_gs[gp::GS_COUNT] = {0};
+  // phase 2
+  double* Rpart = nullptr;    // [p2_slices][Mp][CXp]
+  int p2_slices = 0;
+  double* HZp = nullptr;      // [Mp/64][Np][CZp] per-point partials
+  double* gXmu = nullptr;     // [N][Q]
+  double* gXs = nullptr;      // [N][Q]
+  double* gapart = nullptr;   // [blocks][Q] per-block alpha partial sums from the per-point kernel
+  int ga_blocks = 0;
+  // CG vectors (resident): grad_latest/new/old (2,N,Q) each
+  double* g_latest = nullptr;
+  double* g_new = nullptr;
+  double* g_old = nullptr;
+  // timing
+  hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double t_ms[5] = {0, 0, 0, 0, 0};
 };
 
 namespace gp {
 extern thread_local std::string g_create_error;
 int fail(gp_ctx* ctx, int code, const char* fmt, ...);
+
+// psi.hip
+int run_upload_y(gp_ctx* c, const double* dY);
+int run_prep_and_generate(gp_ctx* c);
+int run_phase1(gp_ctx* c);
+int run_phase2(gp_ctx* c);
+// linalg.hip
+int run_global_step(gp_ctx* c);
+int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,
+                          double* Twork /*[batch][128][Mp]*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/);
 }  // namespace gp
 
 #define GP_HIP(ctx, call)                                                                         \

@@ -1,0 +1,382 @@
+// Global step: the replicated M x M algebra on the all-reduced statistics.
+//   Kmm build (kernels.py:72-113), blocked Cholesky of Kmm and A = Kmm + beta*Psi2 with LDS-resident 128x128
+//   diagonal panels, triangular inverse by recursive doubling, explicit inverses (partial_terms.py:60, 95),
+//   the bound (partial_terms.py:436-473), its partials (partial_terms.py:102-138), grad_beta (:340-360) and the
+//   Kmm-dependent parts of grad_Z / grad_alpha / grad_sf2 (:146-160, 207-240, 247-254, 286-333).
+// All matrices are padded to multiples of 128 with an identity block, which leaves log-determinants, inverses
+// and every trace unchanged.
+#include "gp_common.h"
+#include <cmath>
+
+namespace gp {
+
+constexpr int NB = 128;  // panel width = GEMM tile
+
+// ---------------------------------------------------------------------------------------------- diagonal panels
+// Cholesky of the 128x128 diagonal block j of each matrix in the batch, in LDS (128 KB + one column).
+__global__ void __launch_bounds__(1024) potrf_diag_kernel(double* A, long ld, long bstride, int j, double* fail) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* a = sm;
+  double* col = sm + NB * NB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double* blk = A + (long)blockIdx.x * bstride + ((long)j * NB) * ld + (long)j * NB;
+  for (int idx = tid; idx < NB * NB; idx += 1024) a[idx] = blk[(long)(idx >> 7) * ld + (idx & 127)];
+  __syncthreads();
+  for (int jj = 0; jj < NB; ++jj) {
+    double d2 = a[jj * NB + jj];
+    if (!(d2 > 0.0) || !(d2 < 1e300)) {
+      if (tid == 0) fail[blockIdx.x] = 1.0;
+      d2 = 1.0;
+    }
+    const double d = sqrt(d2), inv = 1.0 / d;
+    if (tid >= jj && tid < NB) col[tid] = (tid == jj) ? d : a[tid * NB + jj] * inv;
+    __syncthreads();
+    if (tid >= jj && tid < NB) a[tid * NB + jj] = col[tid];
+    for (int i = jj + 1 + w; i < NB; i += 16) {
+      const double ci = col[i];
+      for (int k = jj + 1 + lane; k <= i; k += 64) a[i * NB + k] -= ci * col[k];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < NB * NB; idx += 1024) {
+    const int r = idx >> 7, c = idx & 127;
+    blk[(long)r * ld + c] = (c <= r) ? a[idx] : 0.0;
+  }
+}
+
+// inverse of the lower-triangular 128x128 diagonal block j by recursive doubling:
+//   [X11 0; X21 X22] with X21 = -X22 (L21 X11), block size 1, 2, 4, ... 64 -- 7 levels, 2 barriers each.
+__global__ void __launch_bounds__(1024) trinv_diag_kernel(const double* L, long ld, long bstride, int j, double* Linv) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* X = sm;
+  double* T = sm + NB * NB;
+  const int tid = threadIdx.x;
+  const long off = (long)blockIdx.x * bstride + ((long)j * NB) * ld + (long)j * NB;
+  for (int idx = tid; idx < NB * NB; idx += 1024) X[idx] = L[off + (long)(idx >> 7) * ld + (idx & 127)];
+  __syncthreads();
+  if (tid < NB) X[tid * NB + tid] = 1.0 / X[tid * NB + tid];
+  __syncthreads();
+  for (int ls = 0; ls < 7; ++ls) {
+    const int s = 1 << ls;
+    const int outs = 64 * s;  // (128 / 2s) pairs x s x s
+    for (int o = tid; o < outs; o += 1024) {
+      const int p = o >> (2 * ls), r = (o >> ls) & (s - 1), c = o & (s - 1);
+      const int R0 = (2 * p + 1) * s, C0 = 2 * p * s;
+      double sum = 0.0;
+      for (int k = c; k < s; ++k) sum += X[(R0 + r) * NB + C0 + k] * X[(C0 + k) * NB + C0 + c];
+      T[o] = sum;
+    }
+    __syncthreads();
+    for (int o = tid; o < outs; o += 1024) {
+      const int p = o >> (2 * ls), r = (o >> ls) & (s - 1), c = o & (s - 1);
+      const int R0 = (2 * p + 1) * s, C0 = 2 * p * s;
+      double sum = 0.0;
+      for (int k = 0; k <= r; ++k) sum += X[(R0 + r) * NB + R0 + k] * T[(p << (2 * ls)) + (k << ls) + c];
+      X[(R0 + r) * NB + C0 + c] = -sum;
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < NB * NB; idx += 1024) {
+    const int r = idx >> 7, c = idx & 127;
+    Linv[off + (long)r * ld + c] = (c <= r) ? X[idx] : 0.0;
+  }
+}
+
+__global__ void logdet_kernel(const double* L, long ld, long bstride, int n, double* out) {
+  __shared__ double red[256];
+  const double* Lb = L + (long)blockIdx.x * bstride;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += log(Lb[(long)i * ld + i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * red[0];
+}
+
+__global__ void zero_kernel(double* x, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] = 0.0;
+}
+
+static bool g_attr_set = false;
+
+// A: [batch][Mp][Mp] SPD in, lower Cholesky factor out (upper zeroed); Linv: L^-1; Inv: A^-1; Twork: [batch][128][Mp]
+int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A, double* Linv, double* Inv, double* Twork,
+                          double* logdet2, double* fail_flag) {
+  const int nt = Mp / NB;
+  const long ld = Mp, bs = (long)Mp * Mp;
+  if (!g_attr_set) {
+    GP_HIP(c, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + NB) * 8));
+    GP_HIP(c, hipFuncSetAttribute((const void*)trinv_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + 4096) * 8));
+    g_attr_set = true;
+  }
+  hipLaunchKernelGGL(zero_kernel, dim3(1024), dim3(256), 0, st, Linv, bs * batch);
+  for (int j = 0; j < nt; ++j) {
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(1024), (NB * NB + NB) * 8, st, A, ld, bs, j, fail_flag);
+    hipLaunchKernelGGL(trinv_diag_kernel, dim3(batch), dim3(1024), (NB * NB + 4096) * 8, st, A, ld, bs, j, Linv);
+    const int rem = nt - j - 1;
+    if (rem > 0) {
+      // panel: L[i,j] = A[i,j] * inv(L_jj)^T, i > j   (rows rem*128, cols 128, k 128); in place
+      GemmP p;
+      p.A = A + ((long)(j + 1) * NB) * ld + (long)j * NB; p.lda = ld; p.sA = bs;
+      p.B = Linv + ((long)j * NB) * ld + (long)j * NB; p.ldb = ld; p.sB = bs;   // B(k,c) = Xjj[c][k]: stored [c][k] -> K_CONTIG
+      p.C = A + ((long)(j + 1) * NB) * ld + (long)j * NB; p.ldc = ld; p.sC = bs;
+      p.K = NB; p.alpha = 1.0; p.beta = 0.0; p.tri = 0;
+      launch_gemm(st, K_CONTIG, K_CONTIG, rem * NB, NB, batch, p);
+      // trailing update: A[i,k] -= L[i,j] L[k,j]^T for i >= k > j (lower tiles)
+      GemmP q;
+      q.A = A + ((long)(j + 1) * NB) * ld + (long)j * NB; q.lda = ld; q.sA = bs;
+      q.B = q.A; q.ldb = ld; q.sB = bs;                                         // B(k,c) = L[c][k] -> K_CONTIG
+      q.C = A + ((long)(j + 1) * NB) * ld + (long)(j + 1) * NB; q.ldc = ld; q.sC = bs;
+      q.K = NB; q.alpha = -1.0; q.beta = 1.0; q.tri = 1;
+      launch_gemm(st, K_CONTIG, K_CONTIG, rem * NB, rem * NB, batch, q);
+    }
+  }
+  hipLaunchKernelGGL(logdet_kernel, dim3(batch), dim3(256), 0, st, A, ld, bs, Mp, logdet2);
+  // block rows of X = L^-1: X[i,0:i] = -X_ii * (L[i,0:i] * X[0:i,0:i])
+  for (int i = 1; i < nt; ++i) {
+    GemmP p;
+    p.A = A + ((long)i * NB) * ld; p.lda = ld; p.sA = bs;            // L row panel (128 x i*128), K_CONTIG
+    p.B = Linv; p.ldb = ld; p.sB = bs;                               // X[0:i,0:i] stored [k][c] -> FREE_CONTIG
+    p.C = Twork; p.ldc = Mp; p.sC = (long)NB * Mp;
+    p.K = i * NB; p.alpha = 1.0; p.beta = 0.0; p.tri = 0;
+    launch_gemm(st, K_CONTIG, FREE_CONTIG, NB, i * NB, batch, p);
+    GemmP q;
+    q.A = Linv + ((long)i * NB) * ld + (long)i * NB; q.lda = ld; q.sA = bs;   // X_ii, K_CONTIG
+    q.B = Twork; q.ldb = Mp; q.sB = (long)NB * Mp;                            // T stored [k][c] -> FREE_CONTIG
+    q.C = Linv + ((long)i * NB) * ld; q.ldc = ld; q.sC = bs;
+    q.K = NB; q.alpha = -1.0; q.beta = 0.0; q.tri = 0;
+    launch_gemm(st, K_CONTIG, FREE_CONTIG, NB, i * NB, batch, q);
+  }
+  // A^-1 = X^T X
+  GemmP r;
+  r.A = Linv; r.lda = ld; r.sA = bs;   // A(i,k) = X[k][i]: stored [k][i] -> FREE_CONTIG
+  r.B = Linv; r.ldb = ld; r.sB = bs;   // B(k,j) = X[k][j] -> FREE_CONTIG
+  r.C = Inv; r.ldc = ld; r.sC = bs;
+  r.K = Mp; r.alpha = 1.0; r.beta = 0.0; r.tri = 0;
+  launch_gemm(st, FREE_CONTIG, FREE_CONTIG, Mp, Mp, batch, r);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- global step kernels
+// Kmm (kernels.py:108-111) and A = Kmm + beta * Psi2, identity in the padded block
+__global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict__ Z, const double* __restrict__ alpha, double sf2,
+                                                         double beta, const double* __restrict__ Psi2, int M, int Mp, int Q,
+                                                         double* __restrict__ Kmm, double* __restrict__ A, double* __restrict__ Keep) {
+  const long total = (long)Mp * Mp;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+    const int i = (int)(idx / Mp), k = (int)(idx - (long)i * Mp);
+    double v;
+    if (i < M && k < M) {
+      double e = 0.0;
+      for (int q = 0; q < Q; ++q) {
+        const double d = Z[(long)i * Q + q] - Z[(long)k * Q + q];
+        e = fma(alpha[q] * d, d, e);
+      }
+      v = sf2 * exp(-0.5 * e);
+    } else {
+      v = (i == k) ? 1.0 : 0.0;
+    }
+    Kmm[idx] = v;
+    Keep[idx] = v;
+    A[idx] = v + ((i < M && k < M) ? beta * Psi2[idx] : 0.0);
+  }
+}
+
+// sum over the M x M (or M x D) block of x o y; one block per pair, results into out[slot]
+struct DotJob { const double* x; const double* y; long ld; int rows, cols; int slot; };
+struct DotJobs { DotJob j[8]; int n; };
+__global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* out) {
+  __shared__ double red[256];
+  const DotJob jb = jobs.j[blockIdx.x];
+  double s = 0.0;
+  const long total = (long)jb.rows * jb.cols;
+  for (long i = threadIdx.x; i < total; i += 256) {
+    const long r = i / jb.cols, c = i - r * jb.cols;
+    s += jb.x[r * jb.ld + c] * jb.y[r * jb.ld + c];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[jb.slot] = red[0];
+}
+
+// Bbar, dF/dKmm, Abar and the phase-2 operand Bm = [2 Bbar ; Abar^T]
+__global__ void __launch_bounds__(256) assemble_kernel(const double* __restrict__ Ki, const double* __restrict__ P,
+                                                        const double* __restrict__ EEt, const double* __restrict__ KPK,
+                                                        const double* __restrict__ E, double beta, double Dd, int Mp, int Dp,
+                                                        double* __restrict__ Bbar, double* __restrict__ dFdK, double* __restrict__ Abar,
+                                                        double* __restrict__ Bm) {
+  const long mm = (long)Mp * Mp, md = (long)Mp * Dp;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < mm + md; idx += (long)gridDim.x * 256L) {
+    if (idx < mm) {
+      const double kp = Ki[idx] - P[idx];
+      const double b = 0.5 * beta * Dd * kp - 0.5 * beta * beta * beta * EEt[idx];
+      Bbar[idx] = b;
+      dFdK[idx] = 0.5 * Dd * kp - 0.5 * beta * Dd * KPK[idx] - 0.5 * beta * beta * EEt[idx];
+      Bm[idx] = 2.0 * b;
+    } else {
+      const long e = idx - mm;
+      const long m = e / Dp, d = e - m * Dp;
+      const double a = beta * beta * E[e];
+      Abar[e] = a;
+      Bm[mm + d * Mp + m] = a;
+    }
+  }
+}
+
+// F, grad_beta, grad_sf2 from the traces (partial_terms.py:464-472, 346-358, 322-333)
+__global__ void scalars_kernel(const double* sc, double* gs, double beta, double sf2, double Dd, double Nglob) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double sumYY = sc[SC_SUM_YYT], Psi0 = sc[SC_PSI0], KL = sc[SC_KL];
+  const double ldK = gs[GS_LOGDET_K], ldA = gs[GS_LOGDET_A];
+  const double trKi = gs[GS_TR_KIPSI2], trP = gs[GS_TR_PPSI2], trCE = gs[GS_TR_CE], trEPE = gs[GS_TR_EPSI2E];
+  const double two_pi = 6.283185307179586476925286766559;
+  gs[GS_F] = -0.5 * Nglob * Dd * log(two_pi) + 0.5 * Dd * Nglob * log(beta) + 0.5 * Dd * ldK - 0.5 * Dd * ldA - 0.5 * beta * sumYY -
+             0.5 * beta * Dd * Psi0 + 0.5 * beta * Dd * trKi + 0.5 * beta * beta * trCE - KL;
+  gs[GS_GRAD_BETA] = 0.5 * Nglob * Dd / beta - 0.5 * Dd * trP - 0.5 * sumYY - 0.5 * Dd * Psi0 + 0.5 * Dd * trKi + beta * trCE -
+                     0.5 * beta * beta * trEPE;
+  gs[GS_GRAD_SF2] = (gs[GS_SUM_V] + gs[GS_SUM_AC] + 2.0 * gs[GS_SUM_BPSI2] + (-0.5 * beta * Dd) * Psi0) / sf2;
+}
+
+// Kmm-dependent parts: gK[j*Q+k] = -alpha_k sum_m' (dFdK+dFdK^T)[j,m'] Kmm[j,m'] (z_jk - z_m'k)
+//                      gK[M*Q+q] = sum_mm' (-1/2 dFdK o Kmm [- 1/4 Bbar o Psi2 if !regimeA]) (z_mq - z_m'q)^2
+// one block per row j; alpha parts are accumulated per block into gKpart[j][Q] and summed by the caller's reduce
+__global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict__ dFdK, const double* __restrict__ Kmm,
+                                                         const double* __restrict__ Bbar, const double* __restrict__ Psi2,
+                                                         const double* __restrict__ Z, const double* __restrict__ alpha, int M, int Mp,
+                                                         int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart) {
+  __shared__ double red[128];
+  const int j = blockIdx.x;
+  for (int q = 0; q < Q; ++q) {
+    double sz = 0.0, sa = 0.0;
+    const double zj = Z[(long)j * Q + q];
+    for (int m = threadIdx.x; m < M; m += 128) {
+      const double k = Kmm[(long)j * Mp + m];
+      const double dz = zj - Z[(long)m * Q + q];
+      const double sym = (dFdK[(long)j * Mp + m] + dFdK[(long)m * Mp + j]) * k;
+      sz += sym * dz;
+      double w = -0.5 * dFdK[(long)j * Mp + m] * k;
+      if (!regimeA) w += -0.25 * Bbar[(long)j * Mp + m] * Psi2[(long)j * Mp + m];
+      sa += w * dz * dz;
+    }
+    red[threadIdx.x] = sz;
+    __syncthreads();
+    for (int k = 64; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) gZ[(long)j * Q + q] = -alpha[q] * red[0];
+    __syncthreads();
+    red[threadIdx.x] = sa;
+    __syncthreads();
+    for (int k = 64; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) gapart[(long)j * Q + q] = red[0];
+    __syncthreads();
+  }
+}
+__global__ void colsum_kernel(const double* __restrict__ part, int rows, int Q, double* __restrict__ out) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= Q) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += part[(long)r * Q + q];
+  out[q] = s;
+}
+
+int run_global_step(gp_ctx* c) {
+  hipStream_t st = c->stream;
+  const int Mp = c->Mp, Dp = c->Dp, M = c->M, D = c->D, Q = c->Q;
+  const long mm = (long)Mp * Mp;
+  double* Psi2 = c->stats;
+  double* C = c->stats + mm;
+  double* sc = c->stats + mm + (long)Mp * Dp;
+  GP_HIP(c, hipMemsetAsync(c->gs, 0, (GS_COUNT + 8) * sizeof(double), st));
+  double* failf = c->gs + GS_COUNT;  // [2]
+  hipLaunchKernelGGL(build_kmm_kernel, dim3(1024), dim3(256), 0, st, c->Z, c->alpha, c->sf2, c->beta, Psi2, M, Mp, Q, c->Kmm, c->Kmm + mm,
+                     c->KmmKeep);
+  GP_HIP(c, hipGetLastError());
+  // factorise [Kmm ; A] in place, invert.  T1 is the 2 x 128 x Mp work panel.
+  int rc = potrf_inverse_batched(c, st, Mp, 2, c->Kmm, c->Linv, c->Inv, c->T1, c->gs + GS_LOGDET_K, failf);
+  if (rc != GP_OK) return rc;
+  double* Ki = c->Inv;
+  double* P = c->Inv + mm;
+  // E = P C ; PsiE = Psi2 E ; T1 = E E^T ; T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki
+  GemmP g;
+  g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
+  g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
+  launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
+  g.A = Psi2; g.lda = Mp; g.B = c->E; g.ldb = Dp; g.C = c->PsiE; g.ldc = Dp;
+  launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
+  g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
+  launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g);
+  g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
+  launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+  g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;
+  launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+  GP_HIP(c, hipGetLastError());
+  // dFdK currently holds Ki Psi2 Ki; assemble in place is unsafe (reads KPK, writes dFdK at the same index: fine, same thread)
+  hipLaunchKernelGGL(assemble_kernel, dim3(1024), dim3(256), 0, st, Ki, P, c->T1, c->dFdK, c->E, c->beta, (double)D, Mp, Dp, c->Bbar,
+                     c->dFdK, c->Abar, c->Bm);
+  GP_HIP(c, hipGetLastError());
+  DotJobs jobs;
+  jobs.n = 7;
+  jobs.j[0] = {Ki, Psi2, Mp, M, M, GS_TR_KIPSI2};
+  jobs.j[1] = {P, Psi2, Mp, M, M, GS_TR_PPSI2};
+  jobs.j[2] = {C, c->E, Dp, M, D, GS_TR_CE};
+  jobs.j[3] = {c->E, c->PsiE, Dp, M, D, GS_TR_EPSI2E};
+  jobs.j[4] = {c->dFdK, c->KmmKeep, Mp, M, M, GS_SUM_V};
+  jobs.j[5] = {c->Abar, C, Dp, M, D, GS_SUM_AC};
+  jobs.j[6] = {c->Bbar, Psi2, Mp, M, M, GS_SUM_BPSI2};
+  hipLaunchKernelGGL(dots_kernel, dim3(jobs.n), dim3(256), 0, st, jobs, c->gs);
+  hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, c->beta, c->sf2, (double)D, (double)c->N_global);
+  // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
+  hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, st, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
+                     c->regime_A ? 1 : 0, c->gK, c->T2);
+  hipLaunchKernelGGL(colsum_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, c->T2, M, Q, c->gK + (long)M * Q);
+  GP_HIP(c, hipGetLastError());
+  double h[GS_COUNT + 8];
+  GP_HIP(c, hipMemcpyAsync(h, c->gs, sizeof(h), hipMemcpyDeviceToHost, st));
+  GP_HIP(c, hipStreamSynchronize(st));
+  for (int i = 0; i < GS_COUNT; ++i) c->h_gs[i] = h[i];
+  if (h[GS_COUNT] != 0.0) return fail(c, GP_ERR_NOT_PD, "Kmm is not positive definite (Cholesky failed)");
+  if (h[GS_COUNT + 1] != 0.0) return fail(c, GP_ERR_NOT_PD, "Kmm + beta*Psi2 is not positive definite (Cholesky failed)");
+  if (!std::isfinite(h[GS_F])) return fail(c, GP_ERR_NON_FINITE, "bound is not finite");
+  return GP_OK;
+}
+
+}  // namespace gp
+
+// ---- test hook -------------------------------------------------------------------------------------------------
+extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet) {
+  using namespace gp;
+  gp_ctx tmp;
+  gp_ctx* c = &tmp;
+  if (n <= 0 || !A) return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_potrf_inverse: bad argument");
+  GP_HIP(c, hipSetDevice(device));
+  const int Mp = (int)round_up(n, NB);
+  const long mm = (long)Mp * Mp;
+  std::vector<double> h(mm, 0.0);
+  for (int i = 0; i < Mp; ++i) for (int k = 0; k < Mp; ++k) h[(long)i * Mp + k] = (i < n && k < n) ? A[(long)i * n + k] : (i == k ? 1.0 : 0.0);
+  double *dA, *dLi, *dInv, *dT, *dS;
+  GP_HIP(c, hipMalloc((void**)&dA, mm * 8)); GP_HIP(c, hipMalloc((void**)&dLi, mm * 8)); GP_HIP(c, hipMalloc((void**)&dInv, mm * 8));
+  GP_HIP(c, hipMalloc((void**)&dT, (long)NB * Mp * 8)); GP_HIP(c, hipMalloc((void**)&dS, 64));
+  GP_HIP(c, hipMemcpy(dA, h.data(), mm * 8, hipMemcpyHostToDevice));
+  GP_HIP(c, hipMemset(dS, 0, 64));
+  int rc = potrf_inverse_batched(c, nullptr, Mp, 1, dA, dLi, dInv, dT, dS, dS + 1);
+  if (rc == GP_OK) {
+    double s[2];
+    GP_HIP(c, hipDeviceSynchronize());
+    GP_HIP(c, hipMemcpy(s, dS, 16, hipMemcpyDeviceToHost));
+    if (logdet) *logdet = s[0];
+    if (L) { GP_HIP(c, hipMemcpy(h.data(), dA, mm * 8, hipMemcpyDeviceToHost)); for (int i = 0; i < n; ++i) for (int k = 0; k < n; ++k) L[(long)i * n + k] = (k <= i) ? h[(long)i * Mp + k] : 0.0; }
+    if (Ainv) { GP_HIP(c, hipMemcpy(h.data(), dInv, mm * 8, hipMemcpyDeviceToHost)); for (int i = 0; i < n; ++i) for (int k = 0; k < n; ++k) Ainv[(long)i * n + k] = h[(long)i * Mp + k]; }
+    if (s[1] != 0.0) rc = fail(nullptr, GP_ERR_NOT_PD, "matrix is not positive definite");
+  } else {
+    gp::g_create_error = c->err;
+  }
+  (void)hipFree(dA); (void)hipFree(dLi); (void)hipFree(dInv); (void)hipFree(dT); (void)hipFree(dS);
+  return rc;
+}

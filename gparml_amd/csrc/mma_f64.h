@@ -23,8 +23,9 @@ namespace gp {
 constexpr int TILE = 128;          // workgroup output tile (rows and cols), 4 waves as 2x2 of 64x64
 constexpr int WT = 64;             // wave tile
 constexpr int KC = 16;             // k-chunk staged through LDS per iteration
-constexpr int LDS_RC = TILE + 16;  // LDS row stride (doubles) of a [KC][TILE] tile  (operand contiguous along its free index)
-constexpr int TILE_LDS_DOUBLES = KC * LDS_RC;  // 2304 doubles = 18 KB (a [TILE][KC] tile needs only 2048)
+constexpr int LDS_RC = TILE;       // LDS row stride (doubles) of a [KC][TILE] tile (operand contiguous along its free index);
+                                   // unpadded: the 2-way conflict on the 4 A reads per k-step is noise next to 64 MFMAs
+constexpr int TILE_LDS_DOUBLES = KC * TILE;    // 2048 doubles = 16 KB per operand tile
 
 // how an operand tile is stored (in global memory and, identically, in LDS)
 enum Layout : int {

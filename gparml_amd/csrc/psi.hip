@@ -1,0 +1,503 @@
+// Per-shard data kernels: trial-point preparation, Psi1 generation, phase-1 statistics (Psi2 = sum_n psi2_n,
+// C = Psi1^T Y, KL), phase-2 gradient sums.  Reference: kernel_exp.py:13-148, partial_terms.py:38-87, 162-431,
+// local_MapReduce.py:183-248, 310-363.
+#include "gp_common.h"
+#include <algorithm>
+
+namespace gp {
+
+// ------------------------------------------------------------------------------------------------ Y upload
+// Kaug[n][Mp + d] = Y[n][d] (zero padded); one block per row group
+__global__ void __launch_bounds__(256) copy_y_kernel(const double* __restrict__ Y, double* __restrict__ Kaug, long N, long Np, int D,
+                                                     int Dp, int Mp, long ld) {
+  const long total = Np * (long)Dp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long n = i / Dp;
+    const int d = (int)(i - n * Dp);
+    Kaug[n * ld + Mp + d] = (n < N && d < D) ? Y[n * D + d] : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ prep
+// Trial point (local_MapReduce.py:205-214): mu = X_mu + step*d_mu ; S = softplus(X_S_raw + step*d_S) when the
+// variances are stored raw, else S = X_S.  Also ln c1_n (Psi1 normaliser, kernel_exp.py:80), the per-point
+// features Xa = [f1, f2, 1] and the per-block KL partial sums (partial_terms.py:83-85).
+struct PrepArgs {
+  const double* Xmu; const double* Xs; const double* dir; const double* alpha;
+  double* mu; double* S; double* lnc1; double* Xa; double* klpart;
+  long N, Np; int Q, CXp; double step, sf2; int raw, regimeA, fixedA;
+};
+
+__device__ __forceinline__ double softplus(double x) { return log(1.0 + exp(x)); }
+
+__global__ void __launch_bounds__(256) prep_kernel(PrepArgs a) {
+  __shared__ double red[256];
+  double kl = 0.0;
+  for (long n = blockIdx.x * 256L + threadIdx.x; n < a.Np; n += (long)gridDim.x * 256L) {
+    double lnc = log(a.sf2);
+    double klrow = 0.0;
+    for (int q = 0; q < a.Q; ++q) {
+      double m = 0.0, s = 0.0;
+      if (n < a.N) {
+        m = a.Xmu[n * a.Q + q];
+        s = a.Xs[n * a.Q + q];
+        if (a.raw) {
+          if (a.dir && a.step != 0.0) {
+            m += a.step * a.dir[n * a.Q + q];
+            s += a.step * a.dir[(a.N + n) * a.Q + q];
+          }
+          s = softplus(s);
+        }
+      }
+      a.mu[n * a.Q + q] = m;
+      a.S[n * a.Q + q] = s;
+      const double al = a.alpha[q];
+      const double d1 = al * s + 1.0;
+      lnc -= 0.5 * log(d1);
+      const double u = al / d1;
+      double f1, f2;
+      if (a.fixedA) { f1 = m; f2 = m * m; } else { f1 = u * m; f2 = u; }
+      if (n >= a.N) { f1 = 0.0; f2 = 0.0; }
+      a.Xa[n * a.CXp + q] = f1;
+      a.Xa[n * a.CXp + a.Q + q] = f2;
+      if (n < a.N && !a.regimeA) klrow += s - log(s) + m * m - 1.0;
+    }
+    a.Xa[n * a.CXp + 2 * a.Q] = (n < a.N) ? 1.0 : 0.0;
+    for (int c = 2 * a.Q + 1; c < a.CXp; ++c) a.Xa[n * a.CXp + c] = 0.0;
+    a.lnc1[n] = lnc;
+    kl += 0.5 * klrow;
+  }
+  red[threadIdx.x] = kl;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.klpart[blockIdx.x] = red[0];
+}
+
+// ------------------------------------------------------------------------------------------------ Psi1
+// Kaug[n][m] = exp(ln c1_n - 1/2 sum_q u_nq (mu_nq - z_mq)^2), u = alpha/(alpha S + 1)   (kernel_exp.py:80)
+// block: 64 rows x 128 columns; thread: one column, 32 rows; z_m lives in registers for Q <= 16.
+template <int QT>
+__global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ mu, const double* __restrict__ S,
+                                                   const double* __restrict__ lnc1, const double* __restrict__ Z,
+                                                   const double* __restrict__ alpha, double* __restrict__ Kaug, long N, long Np, int M,
+                                                   int Q, long ld) {
+  const int col = blockIdx.x * 128 + (threadIdx.x & 127);
+  const int half = threadIdx.x >> 7;
+  const long row0 = blockIdx.y * 64L + half * 32;
+  double z[QT > 0 ? QT : 1];
+#pragma unroll
+  for (int q = 0; q < QT; ++q) z[q] = (q < Q && col < M) ? Z[(long)col * Q + q] : 0.0;
+  for (int r = 0; r < 32; ++r) {
+    const long n = row0 + r;
+    if (n >= Np) break;
+    double e = 0.0;
+    if (QT > 0) {
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        if (q < Q) {
+          const double al = alpha[q];
+          const double u = al / (al * S[n * Q + q] + 1.0);
+          const double d = mu[n * Q + q] - z[q];
+          e = fma(u * d, d, e);
+        }
+      }
+    } else {
+      for (int q = 0; q < Q; ++q) {
+        const double al = alpha[q];
+        const double u = al / (al * S[n * Q + q] + 1.0);
+        const double d = mu[n * Q + q] - ((col < M) ? Z[(long)col * Q + q] : 0.0);
+        e = fma(u * d, d, e);
+      }
+    }
+    const double v = (n < N && col < M) ? exp(lnc1[n] - 0.5 * e) : 0.0;
+    Kaug[n * ld + col] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ phase 1
+// out[i][j] = sum_n Kaug[n][ti*128 + i] * Kaug[n][tj*128 + j] over the slice's rows: Psi2 tiles (tj < Mp/128,
+// only tj >= ti) and C = Psi1^T Y tiles (tj >= Mp/128).  Split over n into slices; partial tiles are summed by
+// p1_reduce_kernel.  All tile types of one slice sit on one XCD (block b runs on XCD b % 8) so the slice's rows
+// are fetched from HBM once and re-read from that XCD's L2.
+struct P1Args {
+  const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; int psi2_tiles;
+};
+
+__global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int slice = xcd + 8 * (i / p.T), type = i % p.T;
+  if (slice >= p.S) return;
+  const int ti = p.tiles[2 * type], tj = p.tiles[2 * type + 1];
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow0 = (wave >> 1) * WT, wcol0 = (wave & 1) * WT;
+  const bool skip = (ti == tj) && (wave == 2);  // mirror image of wave 1 on a diagonal tile
+  const int c0 = slice * p.cps, c1 = min(p.total_chunks, c0 + p.cps);
+  const double* Ab = p.Kaug + (long)ti * TILE + (long)c0 * KC * p.ld;
+  const double* Bb = p.Kaug + (long)tj * TILE + (long)c0 * KC * p.ld;
+  const long step = (long)KC * p.ld;
+  const int nc = c1 - c0;
+  Acc acc;
+  acc.zero();
+  const LaneOfs ofs = lane_offsets<FREE_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
+  tile_dma<FREE_CONTIG>(lds[0][0], Ab, p.ld, wave, lane);
+  tile_dma<FREE_CONTIG>(lds[0][1], Bb, p.ld, wave, lane);
+  dma_wait();
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nc) {
+      tile_dma<FREE_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * step, p.ld, wave, lane);
+      tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * step, p.ld, wave, lane);
+    }
+    if (!skip) mma_chunk<FREE_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+    dma_wait();
+    __syncthreads();
+  }
+  mfma_drain(acc.v[3][15]);
+  double* out = p.part + ((long)slice * p.T + type) * (TILE * TILE);
+#pragma unroll
+  for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+    for (int bc = 0; bc < 16; ++bc)
+      out[(wrow0 + acc_row(ar, lane)) * TILE + wcol0 + acc_col(bc, lane)] = acc.v[ar][bc];
+}
+
+// sums the slices; writes Psi2 (both triangles) and C into the packed statistics buffer
+__global__ void __launch_bounds__(256) p1_reduce_kernel(const double* __restrict__ part, const int* __restrict__ tiles, int T, int S,
+                                                        double* __restrict__ Psi2, double* __restrict__ C, int Mp, int Dp) {
+  const int type = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;  // element of the 128x128 tile
+  const int r = e >> 7, c = e & 127;
+  const int ti = tiles[2 * type], tj = tiles[2 * type + 1];
+  const int mt = Mp / TILE;
+  if (ti == tj && r >= WT && c < WT) return;  // region skipped by p1_kernel, filled by its mirror
+  double s = 0.0;
+  for (int sl = 0; sl < S; ++sl) s += part[((long)sl * T + type) * (TILE * TILE) + e];
+  if (tj < mt) {
+    const long R = (long)ti * TILE + r, Cc = (long)tj * TILE + c;
+    Psi2[R * Mp + Cc] = s;
+    if (ti != tj || (r < WT && c >= WT)) Psi2[Cc * Mp + R] = s;
+  } else {
+    C[((long)ti * TILE + r) * Dp + (long)(tj - mt) * TILE + c] = s;
+  }
+}
+
+// scalars at the tail of the stats buffer: sum_YYT, Psi0 = sf2 * N_local, KL, N_local
+__global__ void p1_scalars_kernel(const double* klpart, int nblocks, double sumYY, double sf2, double nlocal, int regimeA, double* sc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double kl = 0.0;
+    for (int i = 0; i < nblocks; ++i) kl += klpart[i];
+    sc[SC_SUM_YYT] = sumYY;
+    sc[SC_PSI0] = sf2 * nlocal;
+    sc[SC_KL] = regimeA ? 0.0 : kl;
+    sc[SC_NLOCAL] = nlocal;
+    for (int i = 4; i < SC_COUNT; ++i) sc[i] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int run_upload_y(gp_ctx* c, const double* dY) {
+  const long total = c->Np * (long)c->Dp;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(copy_y_kernel, dim3(blocks), dim3(256), 0, c->stream, dY, c->Kaug, (long)c->N, (long)c->Np, c->D, c->Dp, c->Mp,
+                     (long)c->LDK);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+template <int QT>
+static void launch_psi1(gp_ctx* c) {
+  dim3 grid(c->Mp / 128, (unsigned)((c->Np + 63) / 64));
+  hipLaunchKernelGGL((psi1_kernel<QT>), grid, dim3(256), 0, c->stream, c->mu, c->S, c->lnc1, c->Z, c->alpha, c->Kaug, (long)c->N,
+                     (long)c->Np, c->M, c->Q, (long)c->LDK);
+}
+
+int run_prep_and_generate(gp_ctx* c) {
+  PrepArgs a;
+  a.Xmu = c->Xmu; a.Xs = c->Xs; a.dir = c->have_dir ? c->dir : nullptr; a.alpha = c->alpha;
+  a.mu = c->mu; a.S = c->S; a.lnc1 = c->lnc1; a.Xa = c->Xa; a.klpart = c->klpart;
+  a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CXp = c->CXp; a.step = c->step; a.sf2 = c->sf2;
+  a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = (c->regime_A && !c->want_emb) ? 1 : 0;
+  hipLaunchKernelGGL(prep_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
+  GP_HIP(c, hipGetLastError());
+  (void)hipEventRecord(c->ev[8], c->stream);
+  if (c->Q <= 4) launch_psi1<4>(c);
+  else if (c->Q <= 10) launch_psi1<10>(c);
+  else if (c->Q <= 16) launch_psi1<16>(c);
+  else launch_psi1<0>(c);
+  (void)hipEventRecord(c->ev[9], c->stream);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+int run_phase1(gp_ctx* c) {
+  const int mt = c->Mp / TILE;
+  // regime A: Psi2 = Psi1^T Psi1 and C tiles; regime B: only the C tiles here (Psi2 comes from the pair kernel)
+  const int first = c->regime_A ? 0 : c->n_tiles - mt * (c->Dp / TILE);
+  const int T = c->n_tiles - first;
+  P1Args p;
+  p.Kaug = c->Kaug; p.ld = c->LDK; p.tiles = c->tiles + 2 * first; p.T = T;
+  p.total_chunks = (int)(c->Np / KC);
+  int S = std::max(1, std::min(512 / std::max(T, 1), p.total_chunks));
+  p.cps = (p.total_chunks + S - 1) / S;
+  S = (p.total_chunks + p.cps - 1) / p.cps;
+  p.S = S; p.part = c->part; p.psi2_tiles = 0;
+  const int blocks = 8 * ((S + 7) / 8) * T;
+  (void)hipEventRecord(c->ev[10], c->stream);
+  hipLaunchKernelGGL(p1_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+  (void)hipEventRecord(c->ev[11], c->stream);
+  GP_HIP(c, hipGetLastError());
+  double* Psi2 = c->stats;
+  double* C = c->stats + (long)c->Mp * c->Mp;
+  hipLaunchKernelGGL(p1_reduce_kernel, dim3(TILE * TILE / 256, T), dim3(256), 0, c->stream, c->part, p.tiles, T, S, Psi2, C, c->Mp, c->Dp);
+  GP_HIP(c, hipGetLastError());
+  hipLaunchKernelGGL(p1_scalars_kernel, dim3(1), dim3(64), 0, c->stream, c->klpart, c->kl_blocks, c->sumYY, c->sf2, (double)c->N,
+                     c->regime_A ? 1 : 0, c->stats + (long)c->Mp * c->Mp + (long)c->Mp * c->Dp);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ phase 2
+// G = [Psi1 | Y] * [2 Bbar ; Abar^T]  (regime A; regime B uses only the Y block: G = Y Abar^T), W = G o Psi1, then
+//   R[m][c]  = sum_n W[n][m] Xa[n][c]    (n-contraction: grad_Z / grad_alpha sums, partial_terms.py:162-188, 256-271)
+//   HZ[n][c] = sum_m W[n][m] Zaug[m][c]  (m-contraction: per-point terms of grad_X_mu / grad_X_S / grad_alpha, :367-431)
+// A workgroup owns one 128-wide m tile and walks the 128-row n tiles of its slice; the four m tiles of a slice share
+// an XCD so the Kaug rows come from HBM once.  W goes through LDS in 16-row slabs to become an MFMA operand.
+struct P2Args {
+  const double* Kaug; long ld; const double* Bm; const double* Xa; const double* Zaug;
+  double* Rpart; double* HZp;
+  int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend; long Np;
+};
+
+constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
+constexpr int GRP = 6;        // feature columns are processed 24 at a time (6 B registers)
+
+template <bool PPATH>
+__global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
+  if (slice >= p.S) return;
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int wrow0 = wr * WT, wcol0 = wc * WT;
+  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
+  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4);   // row inside a 16-row group held by this lane's accumulators
+  double* slab = &lds[0][0][0] + wave * (16 * SLAB_LD);
+  const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
+  const int nc = p.kend - p.kbeg;
+  const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
+  const int ngx = (p.CXp / 4 + GRP - 1) / GRP, ngz = (p.CZp / 4 + GRP - 1) / GRP;
+  double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
+  for (int nt = t0; nt < t1; ++nt) {
+    const long n0 = (long)nt * TILE;
+    const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;                  // rows n, k contiguous
+    const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;         // rows k, m contiguous
+    Acc acc;
+    acc.zero();
+    tile_dma<K_CONTIG>(lds[0][0], Ab, p.ld, wave, lane);
+    tile_dma<FREE_CONTIG>(lds[0][1], Bb, p.Mp, wave, lane);
+    dma_wait();
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      const int cur = c & 1;
+      if (c + 1 < nc) {
+        tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
+        tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
+      }
+      mma_chunk<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+      dma_wait();
+      __syncthreads();
+    }
+    mfma_drain(acc.v[3][15]);
+    // W = G o Psi1 (same element positions as the accumulators)
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) {
+      const double* krow = p.Kaug + (n0 + wrow0 + 16 * ar + srow) * p.ld + (long)mt * TILE + wcol0 + lj;
+#pragma unroll
+      for (int bc = 0; bc < 16; ++bc) acc.v[ar][bc] *= krow[4 * bc];
+    }
+    // ---- n-contraction: R[m][c] += sum_n W[n][m] Xa[n][c]
+    for (int g = 0; g < ngx; ++g) {
+      double r[4][GRP];
+#pragma unroll
+      for (int am = 0; am < 4; ++am)
+#pragma unroll
+        for (int bc = 0; bc < GRP; ++bc) r[am][bc] = 0.0;
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar) {
+#pragma unroll
+        for (int bc = 0; bc < 16; ++bc) slab[srow * SLAB_LD + 4 * bc + lj] = acc.v[ar][bc];
+        const double* xrow = p.Xa + (n0 + wrow0 + 16 * ar) * p.CXp + 4 * GRP * g + lj;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          double a[4], b[GRP];
+#pragma unroll
+          for (int am = 0; am < 4; ++am) a[am] = slab[(4 * k4 + lk) * SLAB_LD + 16 * am + lr];
+#pragma unroll
+          for (int bc = 0; bc < GRP; ++bc) b[bc] = (4 * (GRP * g + bc) < p.CXp) ? xrow[(long)(4 * k4 + lk) * p.CXp + 4 * bc] : 0.0;
+#pragma unroll
+          for (int am = 0; am < 4; ++am)
+#pragma unroll
+            for (int bc = 0; bc < GRP; ++bc) mfma444_acc(r[am][bc], a[am], b[bc]);
+        }
+      }
+      mfma_drain(r[3][GRP - 1]);
+      // this wave owns rows [wcol0, wcol0+64) of its (slice, wave-row, m-tile) block of Rpart: plain read-modify-write
+#pragma unroll
+      for (int am = 0; am < 4; ++am)
+#pragma unroll
+        for (int bc = 0; bc < GRP; ++bc) {
+          const int col = 4 * (GRP * g + bc) + lj;
+          if (col < p.CXp) {
+            double* dst = Rmine + (long)(16 * am + srow) * p.CXp + col;
+            *dst = ((nt == t0) ? 0.0 : *dst) + r[am][bc];
+          }
+        }
+    }
+    // ---- m-contraction: HZ[n][c] = sum_m W[n][m] Zaug[m][c]  (this wave's 64 columns only; partials summed later)
+    if (PPATH) {
+      double* hz = p.HZp + ((long)(mt * 2 + wc) * p.Np + n0 + wrow0) * p.CZp;
+      for (int g = 0; g < ngz; ++g) {
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) {
+          double h[GRP];
+#pragma unroll
+          for (int bc = 0; bc < GRP; ++bc) h[bc] = 0.0;
+#pragma unroll
+          for (int bc = 0; bc < 16; ++bc) slab[srow * SLAB_LD + 4 * bc + lj] = acc.v[ar][bc];
+          const double* zrow = p.Zaug + ((long)mt * TILE + wcol0) * p.CZp + 4 * GRP * g + lj;
+#pragma unroll 4
+          for (int k4 = 0; k4 < 16; ++k4) {
+            const double a = slab[lr * SLAB_LD + 4 * k4 + lk];
+#pragma unroll
+            for (int bc = 0; bc < GRP; ++bc) {
+              const double b = (4 * (GRP * g + bc) < p.CZp) ? zrow[(long)(4 * k4 + lk) * p.CZp + 4 * bc] : 0.0;
+              mfma444_acc(h[bc], a, b);
+            }
+          }
+          mfma_drain(h[GRP - 1]);
+#pragma unroll
+          for (int bc = 0; bc < GRP; ++bc) {
+            const int col = 4 * (GRP * g + bc) + lj;
+            if (col < p.CZp) hz[(long)(16 * ar + srow) * p.CZp + col] = h[bc];
+          }
+        }
+      }
+    }
+    __syncthreads();   // slabs live in the staging buffers the next tile's DMA overwrites
+  }
+}
+
+// R = sum of the (slice, wave-row) partials; then the data parts of grad_Z / grad_alpha
+//   fixedA (Xa = [mu, mu^2, 1]):  gZ = a (R1 - Z R0),  ga = -1/2 sum_m (R2 - 2 Z R1 + Z^2 R0)      [regime A, fixed embeddings]
+//   general (Xa = [u mu, u, 1]):  gZ = R1 - Z R2'  with R1 = W^T(u mu), R2' = W^T u; ga comes from the per-point kernel
+__global__ void __launch_bounds__(64) p2_reduce_kernel(const double* __restrict__ Rpart, int nparts, int Mp, int CXp, int M, int Q,
+                                                       const double* __restrict__ Z, const double* __restrict__ alpha, int fixedA,
+                                                       double* __restrict__ gZ, double* __restrict__ gapart) {
+  const int m = blockIdx.x;
+  __shared__ double R[512];
+  for (int c = threadIdx.x; c < CXp; c += 64) {
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += Rpart[((long)i * Mp + m) * CXp + c];
+    R[c] = s;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < Q; q += 64) {
+    const double z = Z[(long)m * Q + q];
+    if (fixedA) {
+      const double r1 = R[q], r2 = R[Q + q], r0 = R[2 * Q];
+      gZ[(long)m * Q + q] = alpha[q] * (r1 - z * r0);
+      gapart[(long)m * Q + q] = -0.5 * (r2 - 2.0 * z * r1 + z * z * r0);
+    } else {
+      gZ[(long)m * Q + q] = R[q] - z * R[Q + q];
+      gapart[(long)m * Q + q] = 0.0;
+    }
+  }
+}
+
+// per-point finish (general mode): HZ = sum of partials; grad_X_mu, grad_X_S, and the per-point part of grad_alpha
+struct PtArgs {
+  const double* HZp; int nparts; long N, Np; int Q, CZp; const double* mu; const double* S; const double* alpha;
+  double* gmu; double* gS; double* gapart; int regimeA;
+};
+__global__ void __launch_bounds__(256) point_kernel(PtArgs a) {
+  extern __shared__ double red[];   // [256][Q] would be too big; accumulate per thread then reduce per q
+  for (int q = 0; q < a.Q; ++q) {
+    double ga = 0.0;
+    for (long n = blockIdx.x * 256L + threadIdx.x; n < a.N; n += (long)gridDim.x * 256L) {
+      double h = 0.0, hz = 0.0, hz2 = 0.0;
+      for (int i = 0; i < a.nparts; ++i) {
+        const double* row = a.HZp + ((long)i * a.Np + n) * a.CZp;
+        h += row[0]; hz += row[1 + q]; hz2 += row[1 + a.Q + q];
+      }
+      const double m = a.mu[n * a.Q + q], s = a.S[n * a.Q + q], al = a.alpha[q];
+      const double d1 = al * s + 1.0, u = al / d1;
+      const double quad = m * m * h - 2.0 * m * hz + hz2;
+      ga += -0.5 * (quad / (d1 * d1) + (s / d1) * h);
+      a.gmu[n * a.Q + q] = -m - u * (m * h - hz);
+      if (!a.regimeA) a.gS[n * a.Q + q] = -0.5 * (1.0 - 1.0 / s) + 0.5 * u * u * quad - 0.5 * u * h;
+    }
+    red[threadIdx.x] = ga;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) a.gapart[(long)blockIdx.x * a.Q + q] = red[0];
+    __syncthreads();
+  }
+}
+
+__global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, const double* __restrict__ b, int rows_b, int Q, double* __restrict__ out) {
+  const int q = blockIdx.x;
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int r = threadIdx.x; r < rows_a; r += 256) s += a[(long)r * Q + q];
+  if (b) for (int r = threadIdx.x; r < rows_b; r += 256) s += b[(long)r * Q + q];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) out[q] = red[0];
+}
+
+int run_phase2(gp_ctx* c) {
+  const bool ppath = !(c->regime_A && !c->want_emb);
+  P2Args p;
+  p.Kaug = c->Kaug; p.ld = c->LDK; p.Bm = c->Bm; p.Xa = c->Xa; p.Zaug = c->Zaug; p.Rpart = c->Rpart; p.HZp = c->HZp;
+  p.Mp = c->Mp; p.CXp = c->CXp; p.CZp = c->CZp; p.MT = c->Mp / TILE; p.Np = c->Np;
+  p.ntiles = (int)(c->Np / TILE);
+  int S = std::max(1, std::min(c->p2_slices, p.ntiles));
+  p.tps = (p.ntiles + S - 1) / S;
+  S = (p.ntiles + p.tps - 1) / p.tps;
+  p.S = S;
+  p.kbeg = c->regime_A ? 0 : c->Mp / KC;
+  p.kend = c->LDK / KC;
+  const int blocks = 8 * ((S + 7) / 8) * p.MT;
+  (void)hipEventRecord(c->ev[12], c->stream);
+  if (ppath) hipLaunchKernelGGL((p2_kernel<true>), dim3(blocks), dim3(256), 0, c->stream, p);
+  else hipLaunchKernelGGL((p2_kernel<false>), dim3(blocks), dim3(256), 0, c->stream, p);
+  (void)hipEventRecord(c->ev[13], c->stream);
+  GP_HIP(c, hipGetLastError());
+  double* gZ = c->grads;
+  double* ga = c->grads + (long)c->M * c->Q;
+  // T2 is free after the global step: per-row alpha partials [M][Q]
+  hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(64), 0, c->stream, c->Rpart, 2 * S, c->Mp, c->CXp, c->M, c->Q, c->Z, c->alpha,
+                     ppath ? 0 : 1, gZ, c->T2);
+  GP_HIP(c, hipGetLastError());
+  if (ppath) {
+    PtArgs a;
+    a.HZp = c->HZp; a.nparts = 2 * p.MT; a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CZp = c->CZp; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
+    a.gmu = c->gXmu; a.gS = c->gXs; a.gapart = c->gapart; a.regimeA = c->regime_A ? 1 : 0;
+    hipLaunchKernelGGL(point_kernel, dim3(c->ga_blocks), dim3(256), 256 * sizeof(double), c->stream, a);
+    GP_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->gapart, c->ga_blocks, c->Q, ga);
+  } else {
+    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, (const double*)nullptr, 0, c->Q, ga);
+  }
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+}  // namespace gp

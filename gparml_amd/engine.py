@@ -1,0 +1,163 @@
+"""One data shard resident on one GPU: the two-phase bound+gradient evaluation.
+
+    phase1 (statistics_mapper, local_MapReduce.py:183-248)  -> packed statistics  [all-reduce]
+    global_step (parallel_GPLVM.py:302-369)                 -> F, dF_d*, grad_beta, Kmm parts
+    phase2 (embeddings_mapper, local_MapReduce.py:310-363 + the Z/alpha sums) -> packed gradient sums [all-reduce]
+    finish                                                  -> grad_Z, grad_alpha, grad_sf2, grad_beta
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class ShardEngine(object):
+    def __init__(self, N_s, D, M, Q, device=0):
+        self.lib = _lib.load()
+        self.N_s, self.D, self.M, self.Q, self.device = int(N_s), int(D), int(M), int(Q), int(device)
+        h = ctypes.c_void_p()
+        rc = self.lib.gp_create(ctypes.byref(h), self.device, self.N_s, self.D, self.M, self.Q)
+        _lib.raise_for(rc, self.lib, None, 'gp_create')
+        self.h = h
+        self._keep = []
+
+    # ---- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.gp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        _lib.raise_for(rc, self.lib, self.h, what)
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.gp_set_stream(self.h, ctypes.c_void_p(stream_ptr)), 'gp_set_stream')
+
+    # ---- data -------------------------------------------------------------------------------------
+    def upload_shard(self, Y, X_mu, X_S, xs_is_raw=False):
+        Y = np.asarray(Y, dtype=np.float64)
+        if Y.ndim == 1:
+            Y = Y[:, None]
+        assert Y.shape == (self.N_s, self.D), 'Y shape %s != (%d, %d)' % (Y.shape, self.N_s, self.D)
+        X_mu = np.asarray(X_mu, dtype=np.float64)
+        X_S = np.asarray(X_S, dtype=np.float64)
+        assert X_mu.ndim == 2 and X_S.ndim == 2 and X_mu.shape == X_S.shape == (self.N_s, self.Q)   # kernel_exp.py:32-34
+        Y, pY = _lib.as_c(Y)
+        X_mu, pm = _lib.as_c(X_mu)
+        X_S, ps = _lib.as_c(X_S)
+        self._ck(self.lib.gp_upload_shard(self.h, pY, pm, ps, 1 if xs_is_raw else 0), 'gp_upload_shard')
+
+    def upload_embeddings(self, X_mu, X_S, xs_is_raw=False):
+        X_mu = np.asarray(X_mu, dtype=np.float64)
+        X_S = np.asarray(X_S, dtype=np.float64)
+        assert X_mu.shape == X_S.shape == (self.N_s, self.Q)
+        X_mu, pm = _lib.as_c(X_mu)
+        X_S, ps = _lib.as_c(X_S)
+        self._ck(self.lib.gp_upload_embeddings(self.h, pm, ps, 1 if xs_is_raw else 0), 'gp_upload_embeddings')
+
+    def set_direction(self, d):
+        if d is None:
+            self._ck(self.lib.gp_set_direction(self.h, None), 'gp_set_direction')
+            return
+        d = np.asarray(d, dtype=np.float64)
+        assert d.shape == (2, self.N_s, self.Q)
+        d, pd = _lib.as_c(d)
+        self._ck(self.lib.gp_set_direction(self.h, pd), 'gp_set_direction')
+
+    def set_globals(self, Z, sf2, alpha, beta, N_global=None, step_size=0.0):
+        Z = np.asarray(Z, dtype=np.float64)
+        assert Z.shape == (self.M, self.Q)
+        alpha = np.atleast_1d(np.asarray(alpha, dtype=np.float64).squeeze())
+        assert alpha.shape == (self.Q,)
+        Z, pZ = _lib.as_c(Z)
+        alpha, pa = _lib.as_c(alpha)
+        Ng = self.N_s if N_global is None else int(N_global)
+        self._ck(self.lib.gp_set_globals(self.h, pZ, float(sf2), pa, float(beta), Ng, float(step_size)), 'gp_set_globals')
+
+    # ---- evaluation ---------------------------------------------------------------------------------
+    def phase1(self):
+        self._ck(self.lib.gp_phase1(self.h), 'gp_phase1')
+
+    def stats_buffer(self):
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._ck(self.lib.gp_stats_buffer(self.h, ctypes.byref(p), ctypes.byref(n)), 'gp_stats_buffer')
+        return p.value, n.value
+
+    def grads_buffer(self):
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._ck(self.lib.gp_grads_buffer(self.h, ctypes.byref(p), ctypes.byref(n)), 'gp_grads_buffer')
+        return p.value, n.value
+
+    def scale_stats(self, factor):
+        self._ck(self.lib.gp_scale_stats(self.h, float(factor)), 'gp_scale_stats')
+
+    def global_step(self):
+        self._ck(self.lib.gp_global_step(self.h), 'gp_global_step')
+
+    def phase2(self, want_embedding_grads=False):
+        self._ck(self.lib.gp_phase2(self.h, 1 if want_embedding_grads else 0), 'gp_phase2')
+
+    def finish(self):
+        F = ctypes.c_double()
+        gs = ctypes.c_double()
+        gb = ctypes.c_double()
+        gZ = np.empty((self.M, self.Q))
+        ga = np.empty(self.Q)
+        self._ck(self.lib.gp_finish(self.h, ctypes.byref(F), gZ.ctypes.data_as(_lib._dp), ctypes.byref(gs),
+                                    ga.ctypes.data_as(_lib._dp), ctypes.byref(gb)), 'gp_finish')
+        return dict(F=F.value, grad_Z=gZ, grad_sf2=gs.value, grad_alpha=ga, grad_beta=gb.value)
+
+    def evaluate(self, want_embedding_grads=False):
+        """Single-shard evaluation (no reduction across shards)."""
+        self.phase1()
+        self.global_step()
+        self.phase2(want_embedding_grads)
+        out = self.finish()
+        if want_embedding_grads:
+            out['grad_X_mu'] = self.download('GRAD_X_MU')
+            if not self.regime_A_hint:
+                out['grad_X_S'] = self.download('GRAD_X_S')
+        return out
+
+    regime_A_hint = False
+
+    def set_local_statistics(self, sum_YYT, Psi2, C, sum_exp_K_ii, KL):
+        Psi2, p2 = _lib.as_c(np.asarray(Psi2, dtype=np.float64).reshape(self.M, self.M))
+        C, pc = _lib.as_c(np.asarray(C, dtype=np.float64).reshape(self.M, self.D))
+        self._ck(self.lib.gp_set_local_statistics(self.h, float(sum_YYT), p2, pc, float(sum_exp_K_ii), float(KL)),
+                 'gp_set_local_statistics')
+
+    def timings(self):
+        t = np.zeros(8)
+        self._ck(self.lib.gp_last_timings(self.h, t.ctypes.data_as(_lib._dp)), 'gp_last_timings')
+        return dict(generate_ms=t[0], phase1_ms=t[1], global_ms=t[2], phase2_ms=t[3], total_ms=t[4],
+                    psi1_ms=t[5], p1_kernel_ms=t[6], p2_kernel_ms=t[7])
+
+    # ---- results ------------------------------------------------------------------------------------
+    _SHAPES = {
+        'KMM': lambda s: (s.M, s.M), 'KMM_INV': lambda s: (s.M, s.M), 'PSI1': lambda s: (s.N_s, s.M),
+        'PSI2_SUM': lambda s: (s.M, s.M), 'PSI1TY': lambda s: (s.M, s.D), 'KMM_PLUS_OP_INV': lambda s: (s.M, s.M),
+        'DF_DKMM': lambda s: (s.M, s.M), 'DF_DPSI1TY': lambda s: (s.M, s.D), 'DF_DPSI2': lambda s: (s.M, s.M),
+        'GRAD_X_MU': lambda s: (s.N_s, s.Q), 'GRAD_X_S': lambda s: (s.N_s, s.Q), 'SCALARS': lambda s: (8,),
+        'PSI2_POINTS': lambda s: (s.N_s, s.M, s.M), 'DKMM_DZ': lambda s: (s.M, s.Q, s.M),
+        'DPSI1TY_DZ': lambda s: (s.M, s.Q, s.D), 'DPSI2_DZ': lambda s: (s.M, s.Q, s.M),
+        'DKMM_DALPHA': lambda s: (s.Q, s.M, s.M), 'DPSI1TY_DALPHA': lambda s: (s.Q, s.M, s.D),
+        'DPSI2_DALPHA': lambda s: (s.Q, s.M, s.M), 'X_MU_TRIAL': lambda s: (s.N_s, s.Q), 'X_S_TRIAL': lambda s: (s.N_s, s.Q),
+    }
+
+    def download(self, name):
+        shape = self._SHAPES[name](self)
+        out = np.empty(shape, dtype=np.float64)
+        self._ck(self.lib.gp_download(self.h, _lib.ARR[name], out.ctypes.data_as(_lib._dp), out.size), 'gp_download(%s)' % name)
+        return out
+
+    def scalars(self):
+        s = self.download('SCALARS')
+        return dict(sum_YYT=s[0], sum_exp_K_ii=s[1], KL=s[2], logdet_Kmm=s[3], logdet_A=s[4], F=s[5], grad_beta=s[6], grad_sf2=s[7])

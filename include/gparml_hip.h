@@ -116,9 +116,10 @@ int gp_download(gp_ctx* ctx, int which, double* dst, int64_t n_doubles);
 /* set the reduced statistics from the host (partial_terms.set_local_statistics, partial_terms.py:54-61) */
 int gp_set_local_statistics(gp_ctx* ctx, double sum_YYT, const double* Psi2, const double* C,
                             double sum_exp_K_ii, double KL);
-/* per-kernel device time of the last evaluation in milliseconds (HIP events on ctx's stream):
- * out[0]=prep+generate, [1]=phase-1 contraction, [2]=global step, [3]=phase-2, [4]=total */
-int gp_last_timings(gp_ctx* ctx, double* out5);
+/* device time of the last evaluation in milliseconds (HIP events on ctx's stream, recorded around each stage):
+ * out[0]=prep+Psi1 generation, [1]=phase-1 contraction+reduce, [2]=global step, [3]=phase 2, [4]=sum of [0..3],
+ * out[5]=psi1_kernel alone, [6]=p1_kernel alone, [7]=p2_kernel alone */
+int gp_last_timings(gp_ctx* ctx, double* out8);
 
 /* ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243), "next" row 8(f)-1 ------------ */
 int gp_cg_set_grads(gp_ctx* ctx);                              /* embeddings_set_grads        :29-55   */

@@ -1,0 +1,142 @@
+"""GPU parity tests proper (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs and against the golden vectors captured from the
+imported reference.
+
+Tolerances (BASELINE.json north_star): bound within 1e-6 relative, gradients within 1e-5 relative to the
+largest magnitude of the gradient block.  The cancellation between the data part and the Kmm part of grad_Z
+grows with cond(Kmm + beta*Psi2); cases are chosen with cond <~ 1e8 (the same limit applies to the reference:
+Cholesky-vs-LU on the CPU differ by the same amount)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+F_RTOL = 1e-6
+G_RTOL = 1e-5
+
+
+def _engine(inp_or_shapes):
+    from gparml_amd.engine import ShardEngine
+    return ShardEngine(*inp_or_shapes)
+
+
+def _run(Z, sf2, alpha, beta, Y, X_mu, X_S, N_global=None, emb=True):
+    N, D = Y.shape
+    M, Q = Z.shape
+    eng = _engine((N, D, M, Q))
+    eng.upload_shard(Y, X_mu, X_S)
+    eng.set_globals(Z, sf2, alpha, beta, N_global=N_global)
+    eng.phase1()
+    eng.global_step()
+    eng.phase2(emb)
+    out = eng.finish()
+    out['stats'] = dict(Psi2=eng.download('PSI2_SUM'), C=eng.download('PSI1TY'), scal=eng.scalars(), Psi1=eng.download('PSI1'))
+    out['partials'] = dict(Abar=eng.download('DF_DPSI1TY'), Bbar=eng.download('DF_DPSI2'), dFdK=eng.download('DF_DKMM'),
+                           Kmm=eng.download('KMM'), Kmm_inv=eng.download('KMM_INV'), P=eng.download('KMM_PLUS_OP_INV'))
+    if emb:
+        out['grad_X_mu'] = eng.download('GRAD_X_MU')
+        if not np.all(X_S == 0):
+            out['grad_X_S'] = eng.download('GRAD_X_S')
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_against_reference_golden(name):
+    """Every golden case captured from the imported reference (tests/golden/make_golden.py)."""
+    inp, ref = load_golden(name)
+    out = _run(inp['Z'], inp['sf2'], inp['alpha'], inp['beta'], inp['Y'], inp['X_mu'], inp['X_S'], N_global=inp['N'])
+    assert_close(out['stats']['Psi1'], ref['exp_K_mi'], 1e-12, what='exp_K_mi')
+    assert_close(out['stats']['Psi2'], ref['sum_exp_K_mi_K_im'], 1e-11, what='sum_exp_K_mi_K_im')
+    assert_close(out['stats']['C'], ref['exp_K_miY'], 1e-11, what='exp_K_miY')
+    assert_close(out['stats']['scal']['sum_YYT'], ref['sum_YYT'], 1e-12, what='sum_YYT')
+    assert_close(out['stats']['scal']['KL'], ref['KL'], 1e-11, atol=1e-300, what='KL')
+    assert_close(out['partials']['Kmm'], ref['Kmm'], 1e-12, what='Kmm')
+    assert_close(out['partials']['Kmm_inv'], ref['Kmm_inv'], 1e-8, what='Kmm_inv')
+    assert_close(out['partials']['P'], ref['Kmm_plus_op_inv'], 1e-8, what='Kmm_plus_op_inv')
+    assert_close(out['F'], ref['F'], F_RTOL, what='F')
+    assert_close(out['partials']['Abar'], ref['dF_dexp_K_miY'], G_RTOL, what='dF_dexp_K_miY')
+    assert_close(out['partials']['Bbar'], ref['dF_dexp_K_mi_K_im'], G_RTOL, what='dF_dexp_K_mi_K_im')
+    assert_close(out['partials']['dFdK'], ref['dF_dKmm'], G_RTOL, what='dF_dKmm')
+    assert_close(out['grad_Z'], ref['grad_Z'], G_RTOL, what='grad_Z')
+    assert_close(out['grad_alpha'], ref['grad_alpha'], G_RTOL, what='grad_alpha')
+    assert_close(out['grad_sf2'], ref['grad_sf2'], G_RTOL, what='grad_sf2')
+    assert_close(out['grad_beta'], ref['grad_beta'], G_RTOL, what='grad_beta')
+    assert_close(out['grad_X_mu'], ref['grad_X_mu'], G_RTOL, what='grad_X_mu')
+    if 'grad_X_S' in ref:
+        assert_close(out['grad_X_S'], ref['grad_X_S'], G_RTOL, what='grad_X_S')
+
+
+SHAPES = [
+    # N, D, M, Q, regime, alpha   (ragged sizes: nothing is a multiple of the 128/16 tiles)
+    (300, 5, 20, 3, 'A', 0.5), (1000, 7, 130, 10, 'A', 0.3), (777, 3, 5, 2, 'A', 0.7), (2000, 10, 128, 13, 'A', 0.2),
+    (900, 4, 64, 20, 'A', 0.1), (129, 1, 1, 1, 'A', 1.0), (4096, 100, 512, 10, 'A', 0.3),
+    (300, 5, 20, 3, 'B', 0.5), (500, 4, 2, 2, 'B', 0.7), (1000, 7, 130, 10, 'B', 0.3), (257, 2, 1, 1, 'B', 1.0),
+    (640, 3, 33, 13, 'B', 0.2),
+]
+
+
+@pytest.mark.parametrize('N,D,M,Q,regime,alpha', SHAPES)
+def test_against_oracle_on_seeded_inputs(N, D, M, Q, regime, alpha):
+    from oracle import factorised as Fz
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=11, zseed=12, alpha_value=alpha)
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+    out = _run(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+    assert_close(out['stats']['Psi2'], ref['stats']['sum_exp_K_mi_K_im'], 1e-11, what='Psi2')
+    assert_close(out['stats']['C'], ref['stats']['exp_K_miY'], 1e-11, what='C')
+    assert_close(out['F'], ref['F'], F_RTOL, what='F')
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu'):
+        assert_close(out[k], ref[k], G_RTOL, what=k)
+    if regime == 'B':
+        assert_close(out['grad_X_S'], ref['grad_X_S'], G_RTOL, what='grad_X_S')
+
+
+def test_errors_map_to_reference_exceptions():
+    """Non-PD Cholesky -> LinAlgError, negative variance -> AssertionError (scg_adapted.py:55 relies on these)."""
+    from gparml_amd.engine import ShardEngine
+    rs = np.random.RandomState(0)
+    N, D, M, Q = 50, 2, 4, 2
+    Y, X = rs.randn(N, D), rs.randn(N, Q)
+    eng = ShardEngine(N, D, M, Q)
+    with pytest.raises(AssertionError):
+        eng.upload_shard(Y, X, -np.ones((N, Q)))
+    eng.upload_shard(Y, X, np.zeros((N, Q)))
+    Z = np.tile(rs.randn(1, Q), (M, 1))          # identical inducing points: Kmm singular
+    eng.set_globals(Z, 1.0, np.ones(Q), 1.0)
+    eng.phase1()
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.global_step()
+    with pytest.raises(AssertionError):
+        eng.set_globals(rs.randn(M, Q), 1.0, -np.ones(Q), 1.0)
+    eng.close()
+
+
+def test_full_size_properties():
+    """Size-independent properties at a BASELINE-like size (config 2: N=1e5, D=10, M=128, Q=10):
+    shard additivity of the statistics (the map/reduce identity), symmetry of Psi2, and scaling of C in Y."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import factorised as Fz
+    N, D, M, Q = 100000, 10, 128, 10
+    d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=0, zseed=1, alpha_value=0.3)
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    eng.phase1()
+    P2, C = eng.download('PSI2_SUM'), eng.download('PSI1TY')
+    assert np.max(np.abs(P2 - P2.T)) == 0.0
+    eng.close()
+    h = N // 3
+    acc2, accC = 0.0, 0.0
+    for sl in (slice(0, h), slice(h, N)):
+        n = sl.stop - sl.start
+        e = ShardEngine(n, D, M, Q)
+        e.upload_shard(d['Y'][sl] * 2.0, d['X_mu'][sl], d['X_S'][sl])
+        e.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
+        e.phase1()
+        acc2 = acc2 + e.download('PSI2_SUM')
+        accC = accC + e.download('PSI1TY')
+        e.close()
+    assert_close(acc2, P2, 1e-12, what='Psi2 additivity')
+    assert_close(accC, 2.0 * C, 1e-12, what='C linearity in Y')

@@ -161,9 +161,11 @@ extern "C" int gp_destroy(gp_ctx* c) {
   double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
-                    c->HZp, c->gXmu, c->gXs, c->gapart, c->g_latest, c->g_new, c->g_old};
+                    c->HZp, c->gXmu, c->gXs, c->gapart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->lnc2h, c->DZ2,
+                    c->Gpart, c->gapart2};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);
+  if (c->ptiles) (void)hipFree(c->ptiles);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return GP_OK;
@@ -280,8 +282,10 @@ extern "C" int gp_phase1(gp_ctx* c) {
   GP_HIP(c, hipSetDevice(c->device));
   GP_HIP(c, hipEventRecord(c->ev[0], c->stream));
   GP_TRY(run_prep_and_generate(c));
+  if (!c->regime_A) GP_TRY(run_generate_b(c));
   GP_HIP(c, hipEventRecord(c->ev[1], c->stream));
   GP_TRY(run_phase1(c));
+  if (!c->regime_A) GP_TRY(run_phase1_b(c));
   GP_HIP(c, hipEventRecord(c->ev[2], c->stream));
   c->state = 1;
   return GP_OK;
@@ -335,6 +339,7 @@ extern "C" int gp_phase2(gp_ctx* c, int want_embedding_grads) {
     GP_TRY(run_prep_and_generate(c));
   }
   GP_TRY(run_phase2(c));
+  if (!c->regime_A) GP_TRY(run_phase2_b(c));
   GP_HIP(c, hipEventRecord(c->ev[6], c->stream));
   c->state = 3;
   return GP_OK;

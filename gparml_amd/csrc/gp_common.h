@@ -104,6 +104,19 @@ struct gp_ctx {
   double* gXs = nullptr;      // [N][Q]
   double* gapart = nullptr;   // [blocks][Q] per-block alpha partial sums from the per-point kernel
   int ga_blocks = 0;
+  // regime B (variances > 0): pairwise psi2 kernels; allocated on first use
+  bool b_alloc = false;
+  double* LE = nullptr;       // [Np][Mp]  1/2 ln c2_n - 1/2 sum_q w_nq (mu_nq - z_mq)^2   (n-major)
+  double* LET = nullptr;      // [Mp][Np]  same, m-major
+  double* Vn = nullptr;       // [Np][Q]   -1/4 (alpha_q - w_nq)
+  double* Wn = nullptr;       // [Np][Q]   w_nq = alpha_q / (2 alpha_q S_nq + 1)
+  double* lnc2h = nullptr;    // [Np]      1/2 ln c2_n
+  double* DZ2 = nullptr;      // [M][M][Q] (z_mq - z_m'q)^2
+  double* Gpart = nullptr;    // [pb_blocks][M][Q] per-block grad_Z partials of the psi2 part
+  double* gapart2 = nullptr;  // [pb_blocks][Q]
+  int pb_blocks = 0;
+  int* ptiles = nullptr;      // upper-triangular 16x16 tile table for the psi2 pair kernel
+  int n_ptiles = 0;
   // CG vectors (resident): grad_latest/new/old (2,N,Q) each
   double* g_latest = nullptr;
   double* g_new = nullptr;
@@ -122,6 +135,12 @@ int run_upload_y(gp_ctx* c, const double* dY);
 int run_prep_and_generate(gp_ctx* c);
 int run_phase1(gp_ctx* c);
 int run_phase2(gp_ctx* c);
+// psi2.hip (regime B)
+int ensure_regime_b_buffers(gp_ctx* c);
+int run_generate_b(gp_ctx* c);
+int run_phase1_b(gp_ctx* c);
+int run_phase2_b(gp_ctx* c);
+int run_dz2(gp_ctx* c);
 // linalg.hip
 int run_global_step(gp_ctx* c);
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,

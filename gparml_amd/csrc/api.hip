@@ -390,6 +390,20 @@ extern "C" int gp_download(gp_ctx* c, int which, double* dst, int64_t n) {
       dst[3] = c->h_gs[GS_LOGDET_K]; dst[4] = c->h_gs[GS_LOGDET_A]; dst[5] = c->h_gs[GS_F]; dst[6] = c->h_gs[GS_GRAD_BETA]; dst[7] = c->h_gs[GS_GRAD_SF2];
       return GP_OK;
     }
+    case GP_ARR_PSI2_POINTS: case GP_ARR_DKMM_DZ: case GP_ARR_DPSI1TY_DZ: case GP_ARR_DPSI2_DZ: case GP_ARR_DKMM_DALPHA:
+    case GP_ARR_DPSI1TY_DALPHA: case GP_ARR_DPSI2_DALPHA: {
+      double* buf = nullptr; long cnt = 0;
+      GP_TRY(compat_build(c, which, &buf, &cnt));
+      int rc = GP_OK;
+      if (cnt != n) rc = fail(c, GP_ERR_BAD_ARG, "gp_download: expected %ld doubles, got %ld", cnt, (long)n);
+      else {
+        hipError_t e = hipMemcpyAsync(dst, buf, cnt * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, GP_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+      }
+      (void)hipFree(buf);
+      return rc;
+    }
     default: return fail(c, GP_ERR_UNSUPPORTED, "gp_download: array %d not available", which);
   }
 }

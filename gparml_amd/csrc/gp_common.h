@@ -141,6 +141,8 @@ int run_generate_b(gp_ctx* c);
 int run_phase1_b(gp_ctx* c);
 int run_phase2_b(gp_ctx* c);
 int run_dz2(gp_ctx* c);
+// compat.hip
+int compat_build(gp_ctx* c, int which, double** out, long* count);
 // linalg.hip
 int run_global_step(gp_ctx* c);
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,

@@ -121,6 +121,12 @@ int gp_set_local_statistics(gp_ctx* ctx, double sum_YYT, const double* Psi2, con
  * out[5]=psi1_kernel alone, [6]=p1_kernel alone, [7]=p2_kernel alone */
 int gp_last_timings(gp_ctx* ctx, double* out8);
 
+/* partial_terms.grad_Z (which=0, partial_terms.py:207-240) / grad_alpha (which=1, :286-299) from explicitly given parts --
+ * the signature an unmodified parallel_GPLVM.calculate_global_derivatives (:340-351) calls.  Shapes as in the reference:
+ * which=0: dKmm_dX (M,Q,M), dC_dX (M,Q,D), dPsi2_dX (M,Q,M) -> out (M,Q); which=1: (Q,M,M), (Q,M,D), (Q,M,M) -> out (Q) */
+int gp_grad_from_parts(gp_ctx* ctx, int which, const double* dF_dKmm, const double* dKmm_dX, const double* dF_dC, const double* dC_dX,
+                       const double* dF_dPsi2, const double* dPsi2_dX, double* out);
+
 /* ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243), "next" row 8(f)-1 ------------ */
 int gp_cg_set_grads(gp_ctx* ctx);                              /* embeddings_set_grads        :29-55   */
 int gp_cg_dots(gp_ctx* ctx, double* out6);                     /* mu,kappa,theta,|g|^2,gamma  :59-140  */

@@ -12,7 +12,7 @@ GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_ERR_HIP, GP_ERR_STAT
 # gp_download selectors (include/gparml_hip.h)
 ARR = dict(KMM=0, KMM_INV=1, PSI1=2, PSI2_SUM=3, PSI1TY=4, KMM_PLUS_OP_INV=5, DF_DKMM=6, DF_DPSI1TY=7, DF_DPSI2=8,
            GRAD_X_MU=9, GRAD_X_S=10, SCALARS=11, PSI2_POINTS=12, DKMM_DZ=13, DPSI1TY_DZ=14, DPSI2_DZ=15, DKMM_DALPHA=16,
-           DPSI1TY_DALPHA=17, DPSI2_DALPHA=18, X_MU_TRIAL=19, X_S_TRIAL=20)
+           DPSI1TY_DALPHA=17, DPSI2_DALPHA=18, X_MU_TRIAL=19, X_S_TRIAL=20, GRAD_LATEST=21)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p
@@ -32,6 +32,7 @@ SIGNATURES = {
     'gp_phase1': (ctypes.c_int, [_vp]),
     'gp_stats_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     'gp_scale_stats': (ctypes.c_int, [_vp, ctypes.c_double]),
+    'gp_buffer_combine': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
     'gp_global_step': (ctypes.c_int, [_vp]),
     'gp_phase2': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gp_grads_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),

@@ -305,6 +305,38 @@ extern "C" int gp_grads_buffer(gp_ctx* c, void** dev_ptr, int64_t* n) {
   return GP_OK;
 }
 
+__global__ void combine_kernel(double* dst, const double* src, long n, int op) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) dst[i] = (op == 0 ? dst[i] : 0.0) + src[i];
+}
+__global__ void grad_latest_kernel(const double* __restrict__ gmu, const double* __restrict__ gS, const double* __restrict__ Xs,
+                                   const double* __restrict__ dir, long N, int Q, double step, int raw, int have_dir, double* __restrict__ out) {
+  const long nq = N * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nq; i += (long)gridDim.x * 256L) {
+    out[i] = -gmu[i];
+    double g = gS[i];
+    if (raw) {
+      double x = Xs[i];
+      if (have_dir && step != 0.0) x += step * dir[nq + i];
+      g *= 1.0 / (exp(-x) + 1.0);      // transformVar_grad, supporting_functions.py:165-168
+    }
+    out[nq + i] = -g;
+  }
+}
+
+extern "C" int gp_buffer_combine(gp_ctx* dst, const gp_ctx* src, int which, int op) {
+  if (!dst || !src) return GP_ERR_BAD_ARG;
+  if (dst->device != src->device) return fail(dst, GP_ERR_BAD_ARG, "gp_buffer_combine: contexts on different devices");
+  if (dst->M != src->M || dst->Q != src->Q || dst->D != src->D) return fail(dst, GP_ERR_BAD_ARG, "gp_buffer_combine: shape mismatch");
+  GP_HIP(dst, hipSetDevice(dst->device));
+  const long n = which == 0 ? (long)dst->Mp * dst->Mp + (long)dst->Mp * dst->Dp + SC_COUNT : (long)dst->M * dst->Q + dst->Q;
+  if (src->stream != dst->stream) GP_HIP(dst, hipStreamSynchronize(src->stream));
+  hipLaunchKernelGGL(combine_kernel, dim3(blocks_for(n)), dim3(256), 0, dst->stream, which == 0 ? dst->stats : dst->grads,
+                     which == 0 ? src->stats : src->grads, n, op);
+  GP_HIP(dst, hipGetLastError());
+  if (which == 0 && dst->state < 1) dst->state = 1;
+  return GP_OK;
+}
+
 extern "C" int gp_scale_stats(gp_ctx* c, double f) {
   if (!c) return GP_ERR_BAD_ARG;
   if (c->state < 1) return fail(c, GP_ERR_STATE, "gp_scale_stats before gp_phase1");
@@ -381,6 +413,20 @@ extern "C" int gp_download(gp_ctx* c, int which, double* dst, int64_t n) {
     case GP_ARR_GRAD_X_S: return download_matrix(c, c->gXs, Q, N, Q, dst, n);
     case GP_ARR_X_MU_TRIAL: return download_matrix(c, c->mu, Q, N, Q, dst, n);
     case GP_ARR_X_S_TRIAL: return download_matrix(c, c->S, Q, N, Q, dst, n);
+    case GP_ARR_GRAD_LATEST: {
+      if (c->state < 3 || !c->want_emb) return fail(c, GP_ERR_STATE, "GP_ARR_GRAD_LATEST needs gp_phase2(ctx, 1) first");
+      if (n != 2 * N * Q) return fail(c, GP_ERR_BAD_ARG, "GP_ARR_GRAD_LATEST wants %ld doubles", 2 * N * Q);
+      if (c->regime_A) return fail(c, GP_ERR_NON_FINITE, "grad_X_S with X_S == 0 (1/S, partial_terms.py:417)");
+      double* tmp = nullptr;
+      GP_HIP(c, hipMalloc((void**)&tmp, 2 * N * Q * 8));
+      hipLaunchKernelGGL(grad_latest_kernel, dim3(blocks_for(N * Q)), dim3(256), 0, c->stream, c->gXmu, c->gXs, c->Xs, c->dir, N, (int)Q, c->step,
+                         c->xs_raw ? 1 : 0, c->have_dir ? 1 : 0, tmp);
+      hipError_t e = hipMemcpyAsync(dst, tmp, 2 * N * Q * 8, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      (void)hipFree(tmp);
+      if (e != hipSuccess) return fail(c, GP_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+      return GP_OK;
+    }
     case GP_ARR_SCALARS: {
       if (n != 8) return fail(c, GP_ERR_BAD_ARG, "GP_ARR_SCALARS wants 8 doubles");
       double sc[SC_COUNT];

@@ -95,6 +95,10 @@ class ShardEngine(object):
         self._ck(self.lib.gp_grads_buffer(self.h, ctypes.byref(p), ctypes.byref(n)), 'gp_grads_buffer')
         return p.value, n.value
 
+    def combine(self, src, which='stats', op='add'):
+        """dst (self) += src or dst = src for the packed statistics / gradient-sum buffers (same device)."""
+        self._ck(self.lib.gp_buffer_combine(self.h, src.h, 0 if which == 'stats' else 1, 0 if op == 'add' else 1), 'gp_buffer_combine')
+
     def scale_stats(self, factor):
         self._ck(self.lib.gp_scale_stats(self.h, float(factor)), 'gp_scale_stats')
 
@@ -150,6 +154,7 @@ class ShardEngine(object):
         'DPSI1TY_DZ': lambda s: (s.M, s.Q, s.D), 'DPSI2_DZ': lambda s: (s.M, s.Q, s.M),
         'DKMM_DALPHA': lambda s: (s.Q, s.M, s.M), 'DPSI1TY_DALPHA': lambda s: (s.Q, s.M, s.D),
         'DPSI2_DALPHA': lambda s: (s.Q, s.M, s.M), 'X_MU_TRIAL': lambda s: (s.N_s, s.Q), 'X_S_TRIAL': lambda s: (s.N_s, s.Q),
+        'GRAD_LATEST': lambda s: (2, s.N_s, s.Q),
     }
 
     def download(self, name):

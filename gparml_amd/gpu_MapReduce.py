@@ -1,0 +1,260 @@
+"""A MapReduce backend with the function set of the reference's ``local_MapReduce`` module, running on the GPU.
+
+``parallel_GPLVM.py`` selects its backend with ``import local_MapReduce as map_reduce`` (parallel_GPLVM.py:87-95) and
+then calls exactly: ``init, cache, statistics_MR, embeddings_MR, load, save, remove, exists, load_partial_terms,
+load_cache`` (call sites parallel_GPLVM.py:95,167,238,243-244,264,309-314,332,379-404; predict.py:30,35,122-124).
+This module provides the same names, arguments, return values and on-disk artefacts:
+
+    {statistics}/global_statistics_{Z|sf2|alpha|beta}_{i}.npy      read   (written by the caller, :236-238)
+    {statistics}/cache_{Kmm|Kmm_inv}_{i}.npy                       written by cache()
+    {statistics}/accumulated_statistics_{12 keys}_{i}.npy          written by statistics_MR()
+    {embeddings}/{shard}.embedding.npy / .variance.npy / .grad_d.npy   read
+    {embeddings}/{shard}.grad_latest.npy  (2,N_s,Q)                written by embeddings_MR()
+
+Differences by design: each shard's Y is parsed from CSV once and then stays resident in HBM
+(the reference re-parses it in every mapper call, local_MapReduce.py:197,325); mappers run in this process, one
+ShardEngine per shard, instead of a multiprocessing.Pool; Kmm is rebuilt on the device rather than read from the
+cache files.  ``options['gpu_compat_tensors'] = False`` skips the four derivative 3-tensors (the fast driver in
+``gparml_amd.driver`` never needs them).
+"""
+import glob
+import os
+import time
+from os.path import basename
+
+import numpy
+
+from .engine import ShardEngine
+from .partial_terms import partial_terms as _partial_terms
+
+def _f(x):
+    return float(numpy.asarray(x).reshape(-1)[0])
+
+
+# ------------------------------------------------------------------------------------------------- module state
+dropped_out_nodes = []
+non_dropped_out_nodes = []
+_shards = {}          # input file -> dict(engine, N_s)
+
+
+def _reset():
+    for s in _shards.values():
+        s['engine'].close()
+    _shards.clear()
+
+
+# ------------------------------------------------------------------------------------------------- file helpers
+def save(file_name, obj):
+    numpy.save(file_name, obj)                                      # local_MapReduce.py:370-371
+
+
+def load(file_name):
+    return numpy.load(file_name)                                    # local_MapReduce.py:373-374
+
+
+def exists(file_name):
+    return os.path.exists(file_name)                                # local_MapReduce.py:376-377
+
+
+def remove(file_name):
+    if exists(file_name):                                           # local_MapReduce.py:379-381
+        os.remove(file_name)
+
+
+def _input_files(options):
+    return sorted(glob.glob(options['input'] + '/*'))
+
+
+def _read_csv(path):
+    Y = numpy.genfromtxt(path, delimiter=',')                       # local_MapReduce.py:197
+    if Y.ndim == 1:
+        Y = numpy.atleast_2d(Y).T                                   # :198-199
+    return Y
+
+
+# ------------------------------------------------------------------------------------------------- init
+def init(options):
+    """local_MapReduce.init (local_MapReduce.py:27-104): count the points; create embeddings / variances unless
+    loading or using fixed embeddings.  The PCA / random initialisation is one-off host preprocessing (out of the hot
+    path); PPCA / FA initialisers of supporting_functions.py are not provided."""
+    names = sorted(os.listdir(options['input'] + '/'))
+    lengths = []
+    for name in names:
+        with open(options['input'] + '/' + name) as f:
+            lengths.append(sum(1 for line in f if line.strip()))
+    options['N'] = sum(lengths)
+    if not options['fixed_embeddings'] and not options['load']:
+        if options['init'] == 'PCA':
+            Y = numpy.concatenate([_read_csv(options['input'] + '/' + n) for n in names])
+            Yc = Y - Y.mean(axis=0)
+            U, s, Vt = numpy.linalg.svd(Yc, full_matrices=False)
+            X = Yc.dot(Vt[:options['Q']].T)
+            X = X / X.std(axis=0)
+        elif options['init'] == 'random':
+            X = numpy.random.randn(options['N'], options['Q'])
+        else:
+            raise Exception("init '%s' is not provided by the GPU backend (PCA or random)" % options['init'])
+        start = 0
+        for name, n in zip(names, lengths):
+            base = options['embeddings'] + '/' + name
+            save(base + '.embedding.npy', X[start:start + n])
+            v = numpy.clip(0.5 * numpy.ones((n, options['Q'])) + 0.01 * numpy.random.randn(n, options['Q']), 0.001, 1)
+            save(base + '.variance.npy', numpy.log(numpy.exp(v) - 1.0))            # transformVar_back, :90-93
+            start += n
+    if options['fixed_embeddings']:
+        for name, n in zip(names, lengths):
+            base = options['embeddings'] + '/' + name
+            if not exists(base + '.embedding.npy'):
+                raise Exception('No embedding file ' + base + '.embedding.npy')
+            save(base + '.variance.npy', numpy.zeros((n, options['Q'])))             # :94-103
+    return options
+
+
+# ------------------------------------------------------------------------------------------------- shards on the GPU
+def _globals(options):
+    gs = {}
+    for key in options['global_statistics_names']:
+        gs[key] = load(options['statistics'] + '/global_statistics_' + key + '_' + str(options['i']) + '.npy')
+    return gs
+
+
+def _prepare_shard(options, input_file_name, global_statistics):
+    """Everything statistics_mapper / embeddings_mapper do before partial_terms.set_data
+    (local_MapReduce.py:189-214, 315-341): resident Y, embeddings, trial point, globals."""
+    key = os.path.abspath(input_file_name)
+    sh = _shards.get(key)
+    base = options['embeddings'] + '/' + basename(input_file_name)
+    X_mu = load(base + '.embedding.npy')
+    X_S = load(base + '.variance.npy')
+    if sh is None or sh['shape'] != (X_mu.shape[0], options['D'], options['M'], options['Q']):
+        if sh is not None:
+            sh['engine'].close()
+        Y = _read_csv(input_file_name)
+        eng = ShardEngine(Y.shape[0], options['D'], options['M'], options['Q'], device=options.get('device', 0))
+        eng.upload_shard(Y, X_mu, X_S, xs_is_raw=not options['fixed_embeddings'])
+        sh = _shards[key] = dict(engine=eng, shape=(Y.shape[0], options['D'], options['M'], options['Q']))
+    else:
+        eng = sh['engine']
+        eng.upload_embeddings(X_mu, X_S, xs_is_raw=not options['fixed_embeddings'])
+    d = None
+    step = 0.0
+    if not options['fixed_embeddings']:
+        dname = base + '.grad_d.npy'
+        if exists(dname) and options['step_size'] != 0:              # :204-211
+            d = load(dname)
+            step = options['step_size']
+    eng.set_direction(d)
+    eng.set_globals(global_statistics['Z'], _f(global_statistics['sf2']), numpy.squeeze(global_statistics['alpha']).reshape(-1),
+                    _f(global_statistics['beta']), N_global=options['N'], step_size=step)
+    return eng
+
+
+# ------------------------------------------------------------------------------------------------- statistics MR
+BASE_KEYS = ['sum_YYT', 'sum_exp_K_ii', 'sum_exp_K_mi_K_im', 'sum_exp_K_miY', 'sum_KL']
+
+
+def statistics_mapper(arg):
+    """local_MapReduce.statistics_mapper (:183-248) for one shard; returns the 12-key dictionary (arrays, not files)."""
+    input_file_name, options = arg
+    start = time.time()
+    gs = _globals(options)
+    eng = _prepare_shard(options, input_file_name, gs)
+    eng.phase1()
+    sc = eng.scalars()
+    sf2 = _f(gs['sf2'])
+    out = {
+        'sum_YYT': numpy.float64(sc['sum_YYT']),
+        'sum_exp_K_ii': numpy.float64(sc['sum_exp_K_ii']),
+        'sum_exp_K_mi_K_im': eng.download('PSI2_SUM'),
+        'sum_exp_K_miY': eng.download('PSI1TY'),
+        'sum_KL': numpy.float64(sc['KL']),
+    }
+    out['sum_d_exp_K_ii_d_sf2'] = eng.N_s                                           # an int, partial_terms.py:318-320
+    out['sum_d_exp_K_miY_d_sf2'] = out['sum_exp_K_miY'] / sf2
+    out['sum_d_exp_K_mi_K_im_d_sf2'] = 2.0 * out['sum_exp_K_mi_K_im'] / sf2
+    if options.get('gpu_compat_tensors', True):
+        out['sum_d_exp_K_miY_d_Z'] = eng.download('DPSI1TY_DZ')
+        out['sum_d_exp_K_mi_K_im_d_Z'] = eng.download('DPSI2_DZ')
+        out['sum_d_exp_K_miY_d_alpha'] = eng.download('DPSI1TY_DALPHA')
+        out['sum_d_exp_K_mi_K_im_d_alpha'] = eng.download('DPSI2_DALPHA')
+    return out, time.time() - start
+
+
+def statistics_MR(options):
+    """local_MapReduce.statistics_MR (:115-171): map every shard, reduce by key, write accumulated_statistics files."""
+    global non_dropped_out_nodes, dropped_out_nodes
+    input_files = _input_files(options)
+    if options.get('drop_out_fraction', 0) > 0:                                      # :119-129
+        drop = numpy.random.uniform(size=len(input_files)) < options['drop_out_fraction']
+        dropped_out_nodes = numpy.arange(len(input_files))[drop]
+        non_dropped_out_nodes = numpy.arange(len(input_files))[~drop]
+        if len(non_dropped_out_nodes) == 0:
+            non_dropped_out_nodes = [numpy.random.randint(0, len(input_files))]
+            dropped_out_nodes = [i for i in range(len(input_files)) if i != non_dropped_out_nodes[0]]
+        input_files = [input_files[i] for i in non_dropped_out_nodes]
+    mapped, mapper_times = [], []
+    for f in input_files:
+        out, t = statistics_mapper((f, options))
+        mapped.append(out)
+        mapper_times.append(t)
+    files, reducer_times = [], []
+    for key in mapped[0].keys():                                                     # statistics_reducer, :250-277
+        start = time.time()
+        acc = mapped[0][key]
+        for m in mapped[1:]:
+            acc = acc + m[key]
+        if options.get('drop_out_fraction', 0) > 0:
+            acc = acc / (float(len(non_dropped_out_nodes)) / (len(non_dropped_out_nodes) + len(dropped_out_nodes)))
+        name = options['statistics'] + '/accumulated_statistics_' + key + '_' + str(options['i']) + '.npy'
+        save(name, acc)
+        files.append((key, name))
+        reducer_times.append(time.time() - start)
+    return files, mapper_times, reducer_times
+
+
+# ------------------------------------------------------------------------------------------------- embeddings MR
+def embeddings_mapper(arg):
+    """local_MapReduce.embeddings_mapper (:310-363): per-point gradients at the trial point from the GLOBAL sums;
+    writes -[grad_X_mu, grad_X_S * softplus'(raw)] as (2,N_s,Q) to .grad_latest.npy."""
+    input_file_name, options = arg
+    start = time.time()
+    gs = _globals(options)
+    acc = {}
+    for key in BASE_KEYS:
+        acc[key] = load(options['statistics'] + '/accumulated_statistics_' + key + '_' + str(options['i']) + '.npy')
+    eng = _prepare_shard(options, input_file_name, gs)
+    eng.phase1()                                    # Psi1 and the psi2 tables at the trial point (set_data(..., False), :348)
+    eng.set_local_statistics(_f(acc['sum_YYT']), acc['sum_exp_K_mi_K_im'], acc['sum_exp_K_miY'], _f(acc['sum_exp_K_ii']),
+                             _f(acc['sum_KL']))  # :350-354
+    eng.global_step()
+    eng.phase2(True)
+    g = eng.download('GRAD_LATEST')                 # :357-359
+    save(options['embeddings'] + '/' + basename(input_file_name) + '.grad_latest.npy', g)
+    return time.time() - start
+
+
+def embeddings_MR(options):
+    return [embeddings_mapper((f, options)) for f in _input_files(options)]          # :284-308
+
+
+# ------------------------------------------------------------------------------------------------- cache / partial_terms
+def load_partial_terms(options, global_statistics):
+    # local_MapReduce.py:403-409
+    return _partial_terms(global_statistics['Z'], _f(global_statistics['sf2']), numpy.squeeze(global_statistics['alpha']).reshape(-1),
+                          _f(global_statistics['beta']), options['M'], options['Q'], options['N'], options['D'],
+                          update_global_statistics=False, device=options.get('device', 0))
+
+
+def cache(options, global_statistics):
+    # local_MapReduce.py:383-394: Kmm and Kmm_inv once per evaluation, for all nodes
+    pt = load_partial_terms(options, global_statistics)
+    pt.update_global_statistics()
+    save(options['statistics'] + '/cache_Kmm_' + str(options['i']) + '.npy', pt.Kmm)
+    save(options['statistics'] + '/cache_Kmm_inv_' + str(options['i']) + '.npy', pt.Kmm_inv)
+
+
+def load_cache(options, partial_terms):
+    # local_MapReduce.py:396-401
+    Kmm = load(options['statistics'] + '/cache_Kmm_' + str(options['i']) + '.npy')
+    Kmm_inv = load(options['statistics'] + '/cache_Kmm_inv_' + str(options['i']) + '.npy')
+    partial_terms.set_global_statistics(Kmm, Kmm_inv)

@@ -63,7 +63,8 @@ enum {
   GP_ARR_DPSI1TY_DALPHA = 17,/* (Q,M,D) dexp_K_miY_dalpha()               partial_terms.py:256 */
   GP_ARR_DPSI2_DALPHA = 18,  /* (Q,M,M) dexp_K_mi_K_im_dalpha()           partial_terms.py:273 */
   GP_ARR_X_MU_TRIAL = 19,    /* (N_s,Q) X_mu + step*d_mu                  local_MapReduce.py:205-211 */
-  GP_ARR_X_S_TRIAL = 20      /* (N_s,Q) softplus(X_S_raw + step*d_S)      local_MapReduce.py:214 */
+  GP_ARR_X_S_TRIAL = 20,     /* (N_s,Q) softplus(X_S_raw + step*d_S)      local_MapReduce.py:214 */
+  GP_ARR_GRAD_LATEST = 21    /* (2,N_s,Q) -[grad_X_mu, grad_X_S * softplus'(raw trial)], the .grad_latest.npy of local_MapReduce.py:357-360 */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -97,6 +98,9 @@ int gp_phase1(gp_ctx* ctx);
 /* packed device buffer the host all-reduces (sum) across shards: the statistics_reducer
  * (local_MapReduce.py:250-277).  Layout: Psi2 (Mp*Mp) | C (Mp*Dp) | sum_YYT, Psi0, KL, n_local, pad(4) */
 int gp_stats_buffer(gp_ctx* ctx, void** dev_ptr, int64_t* n_doubles);
+/* same-device reduce for several shards in one process (statistics_reducer, local_MapReduce.py:250-277):
+ * which=0 statistics buffer, which=1 phase-2 gradient-sum buffer; op=0 dst += src, op=1 dst = src */
+int gp_buffer_combine(gp_ctx* dst, const gp_ctx* src, int which, int op);
 /* scale the reduced statistics (node drop-out rescale, local_MapReduce.py:263-264) */
 int gp_scale_stats(gp_ctx* ctx, double factor);
 /* calculate_global_statistics + Kmm parts of calculate_global_derivatives (parallel_GPLVM.py:302-369):

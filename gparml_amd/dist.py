@@ -26,7 +26,7 @@ def device_tensor(ptr, n, device):
 class DistributedEvaluator(object):
     """Drives one ShardEngine per rank through phase1 -> all-reduce -> global step -> phase2 -> all-reduce."""
 
-    def __init__(self, engine, group=None, device=None, drop_out=None):
+    def __init__(self, engine, group=None, device=None, force_collectives=False):
         import torch.distributed as dist
         self.dist = dist
         self.engine = engine
@@ -36,6 +36,7 @@ class DistributedEvaluator(object):
         self._stats_t = None
         self._grads_t = None
         self.device = device
+        self.force = force_collectives and dist.is_initialized()
 
     def _tensors(self):
         if self._stats_t is None:
@@ -56,12 +57,12 @@ class DistributedEvaluator(object):
         eng = self.engine
         stats_t, grads_t = self._tensors()
         eng.phase1()
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.all_reduce(stats_t, op=self.dist.ReduceOp.SUM, group=self.group)
         if kept_fraction is not None and kept_fraction != 1.0:
             eng.scale_stats(1.0 / kept_fraction)
         eng.global_step()
         eng.phase2(want_embedding_grads)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.all_reduce(grads_t, op=self.dist.ReduceOp.SUM, group=self.group)
         return eng.finish()

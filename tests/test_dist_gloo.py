@@ -1,0 +1,112 @@
+"""world_size-2 test of the N>1 protocol on CPU (gloo): gparml_amd.dist.DistributedEvaluator drives two ranks, each
+holding its own shard, through phase1 -> all-reduce -> global step -> phase2 -> all-reduce -> finish.  On the GPU box the
+engine is gparml_amd.engine.ShardEngine and the backend is RCCL; here an oracle-backed stand-in with the same method
+set and the same packed-buffer protocol plays the engine, so what is tested is the reduction protocol, the packing and the
+drop-out rescale -- and that 2 ranks reproduce the single-shard result on the concatenated data."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine(object):
+    """Test double with ShardEngine's evaluation methods, computing with oracle/factorised.py (tests only)."""
+
+    def __init__(self, d, sl, N_global):
+        from oracle import factorised as Fz
+        self.Fz = Fz
+        self.d = d
+        self.sl = sl
+        self.Ng = N_global
+        M, Q = d['Z'].shape
+        D = d['Y'].shape[1]
+        self.M, self.Q, self.D = M, Q, D
+        self.stats = np.zeros(M * M + M * D + 8)
+        self.grads = np.zeros(M * Q + Q)
+
+    def host_buffers(self):
+        return self.stats, self.grads
+
+    def phase1(self):
+        d, sl = self.d, self.sl
+        s = self.Fz.phase1(d['Z'], d['sf2'], d['alpha'], d['Y'][sl], d['X_mu'][sl], d['X_S'][sl])
+        M, D = self.M, self.D
+        self.stats[:M * M] = s['sum_exp_K_mi_K_im'].ravel()
+        self.stats[M * M:M * M + M * D] = s['exp_K_miY'].ravel()
+        self.stats[M * M + M * D:M * M + M * D + 3] = [s['sum_YYT'], s['sum_exp_K_ii'], s['KL']]
+
+    def scale_stats(self, f):
+        self.stats *= f
+
+    def global_step(self):
+        d, M, D = self.d, self.M, self.D
+        st = dict(sum_exp_K_mi_K_im=self.stats[:M * M].reshape(M, M).copy(), exp_K_miY=self.stats[M * M:M * M + M * D].reshape(M, D).copy(),
+                  sum_YYT=self.stats[M * M + M * D], sum_exp_K_ii=self.stats[M * M + M * D + 1], KL=self.stats[M * M + M * D + 2])
+        self.gs = self.Fz.global_step(d['Z'], d['sf2'], d['alpha'], d['beta'], st, self.Ng, D)
+
+    def phase2(self, want_emb):
+        d, sl = self.d, self.sl
+        p2 = self.Fz.phase2(d['Z'], d['sf2'], d['alpha'], d['Y'][sl], d['X_mu'][sl], d['X_S'][sl], self.gs['Abar'], self.gs['Bbar'],
+                            want_embeddings=want_emb)
+        self.grads[:self.M * self.Q] = p2['grad_Z_data'].ravel()
+        self.grads[self.M * self.Q:] = p2['grad_alpha_data']
+        self.p2 = p2
+
+    def finish(self):
+        acc = dict(grad_Z_data=self.grads[:self.M * self.Q].reshape(self.M, self.Q), grad_alpha_data=self.grads[self.M * self.Q:])
+        return self.Fz.finish(self.d['Z'], self.d['sf2'], self.d['alpha'], self.gs, acc, self.Fz.is_regime_A(self.d['X_S']))
+
+
+def _worker(rank, world, port, regime, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    from gparml_amd.dist import DistributedEvaluator
+    from oracle import factorised as Fz
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    d = Fz.synthetic_shard(90, 4, 7, 3, regime=regime, seed=5, zseed=6, alpha_value=0.5)
+    cut = [0, 37, 90]
+    eng = OracleEngine(d, slice(cut[rank], cut[rank + 1]), 90)
+    ev = DistributedEvaluator(eng)
+    out = ev.evaluate(regime == 'B')
+    out2 = ev.evaluate(regime == 'B', kept_fraction=0.5)      # drop-out rescale path
+    if rank == 0:
+        q.put((out['F'], out['grad_Z'], out['grad_alpha'], out['grad_sf2'], out['grad_beta'], out2['F']))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('regime', ['A', 'B'])
+def test_two_ranks_equal_one_shard(regime):
+    import torch.multiprocessing as mp
+    from oracle import factorised as Fz
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, regime, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    d = Fz.synthetic_shard(90, 4, 7, 3, regime=regime, seed=5, zseed=6, alpha_value=0.5)
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+    assert abs(res[0] - ref['F']) <= 1e-10 * abs(ref['F'])
+    assert np.max(np.abs(res[1] - ref['grad_Z'])) <= 1e-9 * np.max(np.abs(ref['grad_Z']))
+    assert np.max(np.abs(res[2] - ref['grad_alpha'])) <= 1e-9 * np.max(np.abs(ref['grad_alpha']))
+    assert abs(res[3] - ref['grad_sf2']) <= 1e-9 * abs(ref['grad_sf2'])
+    assert abs(res[4] - ref['grad_beta']) <= 1e-9 * abs(ref['grad_beta'])
+    # drop-out rescale (local_MapReduce.py:263-264): statistics divided by kept/(kept+dropped) = 0.5 -> doubled
+    st = Fz.phase1(d['Z'], d['sf2'], d['alpha'], d['Y'], d['X_mu'], d['X_S'])
+    st2 = {k: 2.0 * v for k, v in st.items()}
+    ref2 = Fz.global_step(d['Z'], d['sf2'], d['alpha'], d['beta'], st2, 90, 4)
+    assert abs(res[5] - ref2['F']) <= 1e-10 * abs(ref2['F'])

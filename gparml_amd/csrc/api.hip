@@ -112,7 +112,7 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   auto A = [&](auto** p, size_t n) { if (rc == GP_OK) rc = dalloc(c, p, n); };
   A(&c->Kaug, (size_t)Np * c->LDK);
   A(&c->Xmu, (size_t)N_s * Q); A(&c->Xs, (size_t)N_s * Q); A(&c->dir, (size_t)2 * N_s * Q);
-  A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
+  A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->U, (size_t)Np * Q); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
   A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp);
   A(&c->stats, (size_t)Mp * Mp + Mp * Dp + SC_COUNT);
   A(&c->grads, (size_t)M * Q + Q);
@@ -140,7 +140,7 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   A(&c->Bm, (size_t)c->LDK * Mp);
   A(&c->gs, (size_t)GS_COUNT + 8); A(&c->gK, (size_t)M * Q + Q);
   // phase 2
-  c->p2_slices = std::max(1, std::min<int>(512 / mt, (int)(Np / TILE)));
+  c->p2_slices = std::max(1, std::min<int>(8 * std::max(1, 64 / mt), (int)(Np / TILE)));
   A(&c->Rpart, (size_t)2 * (c->p2_slices + 8) * Mp * c->CXp);
   A(&c->HZp, (size_t)(Mp / WT) * Np * c->CZp);
   A(&c->gXmu, (size_t)N_s * Q); A(&c->gXs, (size_t)N_s * Q);
@@ -158,7 +158,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (!c) return GP_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
+  double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->U, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
                     c->HZp, c->gXmu, c->gXs, c->gapart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->lnc2h, c->DZ2,

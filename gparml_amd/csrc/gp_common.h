@@ -63,6 +63,7 @@ struct gp_ctx {
   double* dir = nullptr;      // [2][N][Q] search direction
   double* mu = nullptr;       // [Np][Q] trial means
   double* S = nullptr;        // [Np][Q] trial variances (actual)
+  double* U = nullptr;        // [Np][Q] u = alpha / (alpha S + 1)
   double* lnc1 = nullptr;     // [Np] ln(sf2) - 1/2 sum ln(a S + 1)
   double* Xa = nullptr;       // [Np][CXp] per-point features for the n-contraction
   double* Z = nullptr;        // [Mp][Q] (rows >= M zero)

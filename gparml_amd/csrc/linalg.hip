@@ -190,21 +190,19 @@ __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict
 struct DotJob { const double* x; const double* y; long ld; int rows, cols; int slot; };
 struct DotJobs { DotJob j[8]; int n; };
 __global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* out) {
+  // grid (64, jobs): 64 blocks per job, atomically combined (out is zeroed by the caller)
   __shared__ double red[256];
-  const DotJob jb = jobs.j[blockIdx.x];
+  const DotJob jb = jobs.j[blockIdx.y];
   double s = 0.0;
-  const long total = (long)jb.rows * jb.cols;
-  for (long i = threadIdx.x; i < total; i += 256) {
-    const long r = i / jb.cols, c = i - r * jb.cols;
-    s += jb.x[r * jb.ld + c] * jb.y[r * jb.ld + c];
-  }
+  for (int r = blockIdx.x; r < jb.rows; r += gridDim.x)
+    for (int c = threadIdx.x; c < jb.cols; c += 256) s += jb.x[(long)r * jb.ld + c] * jb.y[(long)r * jb.ld + c];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) {
     if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[jb.slot] = red[0];
+  if (threadIdx.x == 0) atomicAdd(&out[jb.slot], red[0]);
 }
 
 // Bbar, dF/dKmm, Abar and the phase-2 operand Bm = [2 Bbar ; Abar^T]
@@ -278,12 +276,15 @@ __global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict
     __syncthreads();
   }
 }
-__global__ void colsum_kernel(const double* __restrict__ part, int rows, int Q, double* __restrict__ out) {
-  const int q = blockIdx.x * 64 + threadIdx.x;
-  if (q >= Q) return;
+__global__ void __launch_bounds__(256) colsum_kernel(const double* __restrict__ part, int rows, int Q, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int q = blockIdx.x;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += part[(long)r * Q + q];
-  out[q] = s;
+  for (int r = threadIdx.x; r < rows; r += 256) s += part[(long)r * Q + q];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) out[q] = red[0];
 }
 
 int run_global_step(gp_ctx* c) {
@@ -330,12 +331,12 @@ int run_global_step(gp_ctx* c) {
   jobs.j[4] = {c->dFdK, c->KmmKeep, Mp, M, M, GS_SUM_V};
   jobs.j[5] = {c->Abar, C, Dp, M, D, GS_SUM_AC};
   jobs.j[6] = {c->Bbar, Psi2, Mp, M, M, GS_SUM_BPSI2};
-  hipLaunchKernelGGL(dots_kernel, dim3(jobs.n), dim3(256), 0, st, jobs, c->gs);
+  hipLaunchKernelGGL(dots_kernel, dim3(64, jobs.n), dim3(256), 0, st, jobs, c->gs);
   hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, c->beta, c->sf2, (double)D, (double)c->N_global);
   // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
   hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, st, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
                      c->regime_A ? 1 : 0, c->gK, c->T2);
-  hipLaunchKernelGGL(colsum_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, c->T2, M, Q, c->gK + (long)M * Q);
+  hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, st, c->T2, M, Q, c->gK + (long)M * Q);
   GP_HIP(c, hipGetLastError());
   double h[GS_COUNT + 8];
   GP_HIP(c, hipMemcpyAsync(h, c->gs, sizeof(h), hipMemcpyDeviceToHost, st));

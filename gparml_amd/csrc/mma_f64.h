@@ -23,9 +23,10 @@ namespace gp {
 constexpr int TILE = 128;          // workgroup output tile (rows and cols), 4 waves as 2x2 of 64x64
 constexpr int WT = 64;             // wave tile
 constexpr int KC = 16;             // k-chunk staged through LDS per iteration
-constexpr int LDS_RC = TILE;       // LDS row stride (doubles) of a [KC][TILE] tile (operand contiguous along its free index);
-                                   // unpadded: the 2-way conflict on the 4 A reads per k-step is noise next to 64 MFMAs
-constexpr int TILE_LDS_DOUBLES = KC * TILE;    // 2048 doubles = 16 KB per operand tile
+constexpr int LDS_RC = TILE + 16;  // LDS row stride (doubles) of a [KC][TILE] tile (operand contiguous along its free index):
+                                   // +16 doubles puts the two k-rows a 32-lane read group touches on different bank halves
+                                   // (unpadded, every one of the 20 operand reads per k-step is a 2-way conflict)
+constexpr int TILE_LDS_DOUBLES = KC * LDS_RC;  // 2304 doubles = 18 KB per operand tile (a [TILE][KC] tile uses 2048 of them)
 
 // how an operand tile is stored (in global memory and, identically, in LDS)
 enum Layout : int {
@@ -177,6 +178,17 @@ __device__ __forceinline__ void mma_chunk(const double* sA, const double* sB, Ac
   mma_step(acc, a0, b0);
   __builtin_amdgcn_sched_barrier(0);
   mma_step(acc, a1, b1);
+}
+
+// single-buffered variant (40 fewer VGPRs): for kernels that keep other state live across the k-loop
+template <Layout LA, Layout LB>
+__device__ __forceinline__ void mma_chunk_sb(const double* sA, const double* sB, Acc& acc, const LaneOfs& o) {
+#pragma unroll
+  for (int k4 = 0; k4 < KC / 4; ++k4) {
+    double a[4], b[16];
+    load_operands<LA, LB>(sA, sB, o, k4, a, b);
+    mma_step(acc, a, b);
+  }
 }
 
 }  // namespace gp

@@ -3,6 +3,7 @@
 // local_MapReduce.py:183-248, 310-363.
 #include "gp_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace gp {
 
@@ -24,48 +25,62 @@ __global__ void __launch_bounds__(256) copy_y_kernel(const double* __restrict__ 
 // features Xa = [f1, f2, 1] and the per-block KL partial sums (partial_terms.py:83-85).
 struct PrepArgs {
   const double* Xmu; const double* Xs; const double* dir; const double* alpha;
-  double* mu; double* S; double* lnc1; double* Xa; double* klpart;
+  double* mu; double* S; double* U; double* lnc1; double* Xa; double* klpart;
   long N, Np; int Q, CXp; double step, sf2; int raw, regimeA, fixedA;
 };
 
 __device__ __forceinline__ double softplus(double x) { return log(1.0 + exp(x)); }
 
-__global__ void __launch_bounds__(256) prep_kernel(PrepArgs a) {
+// element-wise part: one thread per (n, q), fully coalesced
+__global__ void __launch_bounds__(256) prep_elem_kernel(PrepArgs a) {
+  const long total = a.Np * a.Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long n = i / a.Q;
+    const int q = (int)(i - n * a.Q);
+    double m = 0.0, s = 0.0;
+    if (n < a.N) {
+      m = a.Xmu[i];
+      s = a.Xs[i];
+      if (a.raw) {
+        if (a.dir && a.step != 0.0) {
+          m += a.step * a.dir[i];
+          s += a.step * a.dir[a.N * a.Q + i];
+        }
+        s = softplus(s);
+      }
+    }
+    a.mu[i] = m;
+    a.S[i] = s;
+    const double al = a.alpha[q];
+    const double u = al / (al * s + 1.0);
+    a.U[i] = u;
+    double f1, f2;
+    if (a.fixedA) { f1 = m; f2 = m * m; } else { f1 = u * m; f2 = u; }
+    if (n >= a.N) { f1 = 0.0; f2 = 0.0; }
+    a.Xa[n * a.CXp + q] = f1;
+    a.Xa[n * a.CXp + a.Q + q] = f2;
+  }
+}
+
+// per-row part: ln c1_n, the constant/padding feature columns, KL partial sums.  Regime A never reads S (it is zero).
+__global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
   __shared__ double red[256];
   double kl = 0.0;
+  const double ln_sf2 = log(a.sf2);
   for (long n = blockIdx.x * 256L + threadIdx.x; n < a.Np; n += (long)gridDim.x * 256L) {
-    double lnc = log(a.sf2);
-    double klrow = 0.0;
-    for (int q = 0; q < a.Q; ++q) {
-      double m = 0.0, s = 0.0;
-      if (n < a.N) {
-        m = a.Xmu[n * a.Q + q];
-        s = a.Xs[n * a.Q + q];
-        if (a.raw) {
-          if (a.dir && a.step != 0.0) {
-            m += a.step * a.dir[n * a.Q + q];
-            s += a.step * a.dir[(a.N + n) * a.Q + q];
-          }
-          s = softplus(s);
-        }
+    double lnc = ln_sf2;
+    if (!a.regimeA) {
+      double klrow = 0.0;
+      for (int q = 0; q < a.Q; ++q) {
+        const double s = a.S[n * a.Q + q], m = a.mu[n * a.Q + q];
+        lnc -= 0.5 * log(a.alpha[q] * s + 1.0);
+        if (n < a.N) klrow += s - log(s) + m * m - 1.0;
       }
-      a.mu[n * a.Q + q] = m;
-      a.S[n * a.Q + q] = s;
-      const double al = a.alpha[q];
-      const double d1 = al * s + 1.0;
-      lnc -= 0.5 * log(d1);
-      const double u = al / d1;
-      double f1, f2;
-      if (a.fixedA) { f1 = m; f2 = m * m; } else { f1 = u * m; f2 = u; }
-      if (n >= a.N) { f1 = 0.0; f2 = 0.0; }
-      a.Xa[n * a.CXp + q] = f1;
-      a.Xa[n * a.CXp + a.Q + q] = f2;
-      if (n < a.N && !a.regimeA) klrow += s - log(s) + m * m - 1.0;
+      kl += 0.5 * klrow;
     }
+    a.lnc1[n] = lnc;
     a.Xa[n * a.CXp + 2 * a.Q] = (n < a.N) ? 1.0 : 0.0;
     for (int c = 2 * a.Q + 1; c < a.CXp; ++c) a.Xa[n * a.CXp + c] = 0.0;
-    a.lnc1[n] = lnc;
-    kl += 0.5 * klrow;
   }
   red[threadIdx.x] = kl;
   __syncthreads();
@@ -78,41 +93,41 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs a) {
 
 // ------------------------------------------------------------------------------------------------ Psi1
 // Kaug[n][m] = exp(ln c1_n - 1/2 sum_q u_nq (mu_nq - z_mq)^2), u = alpha/(alpha S + 1)   (kernel_exp.py:80)
-// block: 64 rows x 128 columns; thread: one column, 32 rows; z_m lives in registers for Q <= 16.
+// block: 64 rows x 128 columns; thread: one column, 32 rows; z_m lives in registers for Q <= 16; the row index is
+// wave-uniform (readfirstlane) so mu / u / ln c1 arrive through scalar loads and feed the FMAs as SGPR operands.
 template <int QT>
-__global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ mu, const double* __restrict__ S,
+__global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ mu, const double* __restrict__ U,
                                                    const double* __restrict__ lnc1, const double* __restrict__ Z,
-                                                   const double* __restrict__ alpha, double* __restrict__ Kaug, long N, long Np, int M,
-                                                   int Q, long ld) {
+                                                   double* __restrict__ Kaug, long N, long Np, int M, int Q, long ld) {
   const int col = blockIdx.x * 128 + (threadIdx.x & 127);
-  const int half = threadIdx.x >> 7;
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
   const long row0 = blockIdx.y * 64L + half * 32;
   double z[QT > 0 ? QT : 1];
 #pragma unroll
   for (int q = 0; q < QT; ++q) z[q] = (q < Q && col < M) ? Z[(long)col * Q + q] : 0.0;
+  const bool colok = col < M;
+#pragma unroll 4
   for (int r = 0; r < 32; ++r) {
     const long n = row0 + r;
     if (n >= Np) break;
+    const double* mrow = mu + n * Q;
+    const double* urow = U + n * Q;
     double e = 0.0;
     if (QT > 0) {
 #pragma unroll
       for (int q = 0; q < QT; ++q) {
         if (q < Q) {
-          const double al = alpha[q];
-          const double u = al / (al * S[n * Q + q] + 1.0);
-          const double d = mu[n * Q + q] - z[q];
-          e = fma(u * d, d, e);
+          const double d = mrow[q] - z[q];
+          e = fma(urow[q] * d, d, e);
         }
       }
     } else {
       for (int q = 0; q < Q; ++q) {
-        const double al = alpha[q];
-        const double u = al / (al * S[n * Q + q] + 1.0);
-        const double d = mu[n * Q + q] - ((col < M) ? Z[(long)col * Q + q] : 0.0);
-        e = fma(u * d, d, e);
+        const double d = mrow[q] - (colok ? Z[(long)col * Q + q] : 0.0);
+        e = fma(urow[q] * d, d, e);
       }
     }
-    const double v = (n < N && col < M) ? exp(lnc1[n] - 0.5 * e) : 0.0;
+    const double v = (n < N && colok) ? exp(lnc1[n] - 0.5 * e) : 0.0;
     Kaug[n * ld + col] = v;
   }
 }
@@ -123,7 +138,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ mu
 // p1_reduce_kernel.  All tile types of one slice sit on one XCD (block b runs on XCD b % 8) so the slice's rows
 // are fetched from HBM once and re-read from that XCD's L2.
 struct P1Args {
-  const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; int psi2_tiles;
+  const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; int psi2_tiles; int dbg;
 };
 
 __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
@@ -134,7 +149,9 @@ __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow0 = (wave >> 1) * WT, wcol0 = (wave & 1) * WT;
-  const bool skip = (ti == tj) && (wave == 2);  // mirror image of wave 1 on a diagonal tile
+  const bool skip = (ti == tj) && (wave == 2) && !(p.dbg & 4);  // mirror image of wave 1 on a diagonal tile
+  if (p.dbg & 8) { if (((blockIdx.x >> 3) & 32) != 0) __builtin_amdgcn_s_setprio(2); }
+  if (p.dbg & 16) { if (((blockIdx.x >> 3) & 1) != 0) __builtin_amdgcn_s_setprio(2); }
   const int c0 = slice * p.cps, c1 = min(p.total_chunks, c0 + p.cps);
   const double* Ab = p.Kaug + (long)ti * TILE + (long)c0 * KC * p.ld;
   const double* Bb = p.Kaug + (long)tj * TILE + (long)c0 * KC * p.ld;
@@ -149,11 +166,11 @@ __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nc) {
+    if (c + 1 < nc && !(p.dbg & 1)) {
       tile_dma<FREE_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * step, p.ld, wave, lane);
       tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * step, p.ld, wave, lane);
     }
-    if (!skip) mma_chunk<FREE_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+    if (!skip && !(p.dbg & 2)) mma_chunk<FREE_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
     dma_wait();
     __syncthreads();
   }
@@ -188,9 +205,14 @@ __global__ void __launch_bounds__(256) p1_reduce_kernel(const double* __restrict
 
 // scalars at the tail of the stats buffer: sum_YYT, Psi0 = sf2 * N_local, KL, N_local
 __global__ void p1_scalars_kernel(const double* klpart, int nblocks, double sumYY, double sf2, double nlocal, int regimeA, double* sc) {
+  __shared__ double red[256];
+  double part = 0.0;
+  if (!regimeA) for (int i = threadIdx.x; i < nblocks; i += 256) part += klpart[i];
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double kl = 0.0;
-    for (int i = 0; i < nblocks; ++i) kl += klpart[i];
+    const double kl = red[0];
     sc[SC_SUM_YYT] = sumYY;
     sc[SC_PSI0] = sf2 * nlocal;
     sc[SC_KL] = regimeA ? 0.0 : kl;
@@ -212,17 +234,18 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 template <int QT>
 static void launch_psi1(gp_ctx* c) {
   dim3 grid(c->Mp / 128, (unsigned)((c->Np + 63) / 64));
-  hipLaunchKernelGGL((psi1_kernel<QT>), grid, dim3(256), 0, c->stream, c->mu, c->S, c->lnc1, c->Z, c->alpha, c->Kaug, (long)c->N,
-                     (long)c->Np, c->M, c->Q, (long)c->LDK);
+  hipLaunchKernelGGL((psi1_kernel<QT>), grid, dim3(256), 0, c->stream, c->mu, c->U, c->lnc1, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M,
+                     c->Q, (long)c->LDK);
 }
 
 int run_prep_and_generate(gp_ctx* c) {
   PrepArgs a;
   a.Xmu = c->Xmu; a.Xs = c->Xs; a.dir = c->have_dir ? c->dir : nullptr; a.alpha = c->alpha;
-  a.mu = c->mu; a.S = c->S; a.lnc1 = c->lnc1; a.Xa = c->Xa; a.klpart = c->klpart;
+  a.mu = c->mu; a.S = c->S; a.U = c->U; a.lnc1 = c->lnc1; a.Xa = c->Xa; a.klpart = c->klpart;
   a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CXp = c->CXp; a.step = c->step; a.sf2 = c->sf2;
   a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = (c->regime_A && !c->want_emb) ? 1 : 0;
-  hipLaunchKernelGGL(prep_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(prep_elem_kernel, dim3((unsigned)std::min<long>((c->Np * c->Q + 255) / 256, 16384)), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(prep_row_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());
   (void)hipEventRecord(c->ev[8], c->stream);
   if (c->Q <= 4) launch_psi1<4>(c);
@@ -242,10 +265,14 @@ int run_phase1(gp_ctx* c) {
   P1Args p;
   p.Kaug = c->Kaug; p.ld = c->LDK; p.tiles = c->tiles + 2 * first; p.T = T;
   p.total_chunks = (int)(c->Np / KC);
-  int S = std::max(1, std::min(512 / std::max(T, 1), p.total_chunks));
+  // slices: a multiple of 8 (block b runs on XCD b % 8 and a slice lives on one XCD) with at most 64 workgroups per XCD,
+  // so that every workgroup is resident at once (a 65th workgroup on an XCD would wait for a whole first round)
+  int S = 8 * std::max(1, 64 / std::max(T, 1));
+  S = std::max(1, std::min(S, p.total_chunks));
   p.cps = (p.total_chunks + S - 1) / S;
   S = (p.total_chunks + p.cps - 1) / p.cps;
   p.S = S; p.part = c->part; p.psi2_tiles = 0;
+  { const char* e = getenv("GP_P1_DBG"); p.dbg = e ? atoi(e) : 0; }
   const int blocks = 8 * ((S + 7) / 8) * T;
   (void)hipEventRecord(c->ev[10], c->stream);
   hipLaunchKernelGGL(p1_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
@@ -255,7 +282,7 @@ int run_phase1(gp_ctx* c) {
   double* C = c->stats + (long)c->Mp * c->Mp;
   hipLaunchKernelGGL(p1_reduce_kernel, dim3(TILE * TILE / 256, T), dim3(256), 0, c->stream, c->part, p.tiles, T, S, Psi2, C, c->Mp, c->Dp);
   GP_HIP(c, hipGetLastError());
-  hipLaunchKernelGGL(p1_scalars_kernel, dim3(1), dim3(64), 0, c->stream, c->klpart, c->kl_blocks, c->sumYY, c->sf2, (double)c->N,
+  hipLaunchKernelGGL(p1_scalars_kernel, dim3(1), dim3(256), 0, c->stream, c->klpart, c->kl_blocks, c->sumYY, c->sf2, (double)c->N,
                      c->regime_A ? 1 : 0, c->stats + (long)c->Mp * c->Mp + (long)c->Mp * c->Dp);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -270,7 +297,7 @@ int run_phase1(gp_ctx* c) {
 struct P2Args {
   const double* Kaug; long ld; const double* Bm; const double* Xa; const double* Zaug;
   double* Rpart; double* HZp;
-  int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend; long Np;
+  int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend; long Np; int dbg;
 };
 
 constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
@@ -293,6 +320,11 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
   const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
   const int ngx = (p.CXp / 4 + GRP - 1) / GRP, ngz = (p.CZp / 4 + GRP - 1) / GRP;
   double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
+  if (p.dbg & 12) {
+    // experiment: stagger the two workgroups of a CU by half a tile so that their epilogues do not coincide
+    const bool late = (p.dbg & 4) ? (((blockIdx.x >> 3) & 32) != 0) : (((blockIdx.x >> 3) & 1) != 0);
+    if (late) { const long t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32); }
+  }
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;                  // rows n, k contiguous
@@ -309,11 +341,12 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
         tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
         tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
       }
-      mma_chunk<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+      if (!(p.dbg & 2)) mma_chunk<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
       dma_wait();
       __syncthreads();
     }
     mfma_drain(acc.v[3][15]);
+    if (p.dbg & 1) { __syncthreads(); continue; }
     // W = G o Psi1 (same element positions as the accumulators)
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) {
@@ -391,6 +424,104 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
     }
     __syncthreads();   // slabs live in the staging buffers the next tile's DMA overwrites
   }
+}
+
+// Fast variant for the fixed-embedding regime (no per-point outputs) and CXp <= 4*NRB <= 24: the n-contraction
+// accumulators R[64 m][CXp] of each wave stay in registers across all n tiles of the slice (no read-modify-write), and
+// every epilogue operand comes from LDS: the Xa tile is staged once per tile, the Psi1 tile arrives by coalesced 16-byte
+// loads (prefetched one 16-row slab ahead) and is re-laid out through the wave's slab.
+template <int NRB>
+__global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
+  if (slice >= p.S) return;
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int wrow0 = wr * WT, wcol0 = wc * WT;
+  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
+  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  double* xa_s = &lds[0][0][0];                                   // [128][CXp]   (<= 24.6 KB)
+  double* slab = &lds[0][0][0] + TILE * 24 + wave * (16 * SLAB_LD);  // per wave [16][66]
+  const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
+  const int nc = p.kend - p.kbeg;
+  const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
+  double r[4][NRB];
+#pragma unroll
+  for (int am = 0; am < 4; ++am)
+#pragma unroll
+    for (int bc = 0; bc < NRB; ++bc) r[am][bc] = 0.0;
+  const int crow = lane >> 2, ccg = lane & 3;                     // coalesced slab load: row, 16-column group
+  for (int nt = t0; nt < t1; ++nt) {
+    const long n0 = (long)nt * TILE;
+    const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
+    const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;
+    Acc acc;
+    acc.zero();
+    tile_dma<K_CONTIG>(lds[0][0], Ab, p.ld, wave, lane);
+    tile_dma<FREE_CONTIG>(lds[0][1], Bb, p.Mp, wave, lane);
+    dma_wait();
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      const int cur = c & 1;
+      if (c + 1 < nc) {
+        tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
+        tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
+      }
+      mma_chunk_sb<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+      dma_wait();
+      __syncthreads();
+    }
+    mfma_drain(acc.v[3][15]);
+    // ---- epilogue: all staging buffers are free now
+    {
+      const double2* src = reinterpret_cast<const double2*>(p.Xa + n0 * p.CXp);
+      double2* dst = reinterpret_cast<double2*>(xa_s);
+      const int n2 = TILE * p.CXp / 2;
+      for (int i = tid; i < n2; i += 256) dst[i] = src[i];
+    }
+    const double* kbase = p.Kaug + (n0 + wrow0 + crow) * p.ld + (long)mt * TILE + wcol0 + 16 * ccg;
+    double2 kv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const double2*>(kbase + 2 * i);
+    __syncthreads();   // xa_s visible to every wave
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(slab + crow * SLAB_LD + 16 * ccg + 2 * i) = kv[i];
+      if (ar < 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const double2*>(kbase + (long)(16 * (ar + 1)) * p.ld + 2 * i);
+      }
+#pragma unroll
+      for (int bc = 0; bc < 16; ++bc) {
+        const double w = acc.v[ar][bc] * slab[srow * SLAB_LD + 4 * bc + lj];
+        slab[srow * SLAB_LD + 4 * bc + lj] = w;    // each lane overwrites exactly the element it read
+      }
+      const double* xrow = xa_s + (wrow0 + 16 * ar) * p.CXp + lj;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        double a[4], b[NRB];
+#pragma unroll
+        for (int am = 0; am < 4; ++am) a[am] = slab[(4 * k4 + lk) * SLAB_LD + 16 * am + lr];
+#pragma unroll
+        for (int bc = 0; bc < NRB; ++bc) b[bc] = xrow[(4 * k4 + lk) * p.CXp + 4 * bc];   // CXp == 4 * NRB
+#pragma unroll
+        for (int am = 0; am < 4; ++am)
+#pragma unroll
+          for (int bc = 0; bc < NRB; ++bc) mfma444_acc(r[am][bc], a[am], b[bc]);
+      }
+    }
+    mfma_drain(r[3][NRB - 1]);   // hipcc may spill r[] around the k-loop: its MFMAs must have retired first
+    __syncthreads();   // slabs / xa_s live in the staging buffers the next tile's DMA overwrites
+  }
+  double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
+#pragma unroll
+  for (int am = 0; am < 4; ++am)
+#pragma unroll
+    for (int bc = 0; bc < NRB; ++bc) {
+      Rmine[(long)(16 * am + srow) * p.CXp + 4 * bc + lj] = (t1 > t0) ? r[am][bc] : 0.0;
+    }
 }
 
 // R = sum of the (slice, wave-row) partials; then the data parts of grad_Z / grad_alpha
@@ -474,10 +605,22 @@ int run_phase2(gp_ctx* c) {
   p.S = S;
   p.kbeg = c->regime_A ? 0 : c->Mp / KC;
   p.kend = c->LDK / KC;
+  { const char* e = getenv("GP_P2_DBG"); p.dbg = e ? atoi(e) : 0; }
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
   (void)hipEventRecord(c->ev[12], c->stream);
+  const bool fast = !ppath && c->CXp <= 24 && !(p.dbg & 16);
   if (ppath) hipLaunchKernelGGL((p2_kernel<true>), dim3(blocks), dim3(256), 0, c->stream, p);
-  else hipLaunchKernelGGL((p2_kernel<false>), dim3(blocks), dim3(256), 0, c->stream, p);
+  else if (!fast) hipLaunchKernelGGL((p2_kernel<false>), dim3(blocks), dim3(256), 0, c->stream, p);
+  else {
+    switch (c->CXp / 4) {
+      case 1: hipLaunchKernelGGL((p2_fast_kernel<1>), dim3(blocks), dim3(256), 0, c->stream, p); break;
+      case 2: hipLaunchKernelGGL((p2_fast_kernel<2>), dim3(blocks), dim3(256), 0, c->stream, p); break;
+      case 3: hipLaunchKernelGGL((p2_fast_kernel<3>), dim3(blocks), dim3(256), 0, c->stream, p); break;
+      case 4: hipLaunchKernelGGL((p2_fast_kernel<4>), dim3(blocks), dim3(256), 0, c->stream, p); break;
+      case 5: hipLaunchKernelGGL((p2_fast_kernel<5>), dim3(blocks), dim3(256), 0, c->stream, p); break;
+      default: hipLaunchKernelGGL((p2_fast_kernel<6>), dim3(blocks), dim3(256), 0, c->stream, p); break;
+    }
+  }
   (void)hipEventRecord(c->ev[13], c->stream);
   GP_HIP(c, hipGetLastError());
   double* gZ = c->grads;

@@ -142,36 +142,42 @@ def test_full_size_properties():
     assert_close(accC, 2.0 * C, 1e-12, what='C linearity in Y')
 
 
+RCCL_SCRIPT = r"""
+import os, socket, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+from gparml_amd.dist import DistributedEvaluator
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+import numpy as np
+s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1)
+N, D, M, Q = 500, 6, 40, 4
+d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=3, zseed=4, alpha_value=0.4)
+eng = ShardEngine(N, D, M, Q)
+eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+ev = DistributedEvaluator(eng, device=torch.device('cuda', 0), force_collectives=True)
+out = ev.evaluate(False)
+st, gt = ev._tensors()
+assert st.is_cuda and st.dtype == torch.float64 and st.data_ptr() == eng.stats_buffer()[0]
+ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=False)
+assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F'])
+assert np.max(np.abs(out['grad_Z'] - ref['grad_Z'])) <= 1e-5 * np.max(np.abs(ref['grad_Z']))
+eng.close()
+dist.destroy_process_group()
+print('RCCL_OK')
+"""
+
+
 def test_rccl_allreduce_on_the_packed_device_buffers():
-    """The N>1 path on one GPU: a 1-rank RCCL group all-reduces the engine's packed device buffers in place
-    (zero-copy torch view of the library's memory) and the evaluation still matches the oracle."""
-    import os
-    import socket
-    import torch
-    import torch.distributed as dist
-    from gparml_amd.dist import DistributedEvaluator
-    from gparml_amd.engine import ShardEngine
-    from oracle import factorised as Fz
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('nccl', rank=0, world_size=1)
-    try:
-        N, D, M, Q = 500, 6, 40, 4
-        d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=3, zseed=4, alpha_value=0.4)
-        eng = ShardEngine(N, D, M, Q)
-        eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
-        eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
-        ev = DistributedEvaluator(eng, device=torch.device('cuda', 0), force_collectives=True)
-        out = ev.evaluate(False)
-        st, gt = ev._tensors()
-        assert st.is_cuda and st.dtype == torch.float64 and st.data_ptr() == eng.stats_buffer()[0]
-        ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=False)
-        assert_close(out['F'], ref['F'], F_RTOL, what='F')
-        assert_close(out['grad_Z'], ref['grad_Z'], G_RTOL, what='grad_Z')
-        eng.close()
-    finally:
-        dist.destroy_process_group()
+    """The N>1 path on one GPU, in a fresh process: a 1-rank RCCL group all-reduces the engine's packed device buffers
+    in place (zero-copy torch view of the library's memory) and the evaluation still matches the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, '-c', RCCL_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

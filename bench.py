@@ -140,7 +140,7 @@ def main():
                        'points_per_sec': world * N * a.steps / dt, 'F': out['F'],
                        'device_ms': {k: round(v, 4) for k, v in kern.items()},
                        'eval_flops_survey_8d': W_eval, 'eval_fraction_of_fp64_peak': W_eval / (kern['total_ms'] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-            'roofline': {'bound': 'mfma', 'kernel': 'gp::p2_kernel', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'roofline': {'bound': 'mfma', 'kernel': 'gp::p2_fast_kernel<6>', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / FP64_PEAK_TFLOPS, 'traffic': traffic},
         }
         if not a.no_cpu_baseline:

@@ -112,7 +112,7 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   auto A = [&](auto** p, size_t n) { if (rc == GP_OK) rc = dalloc(c, p, n); };
   A(&c->Kaug, (size_t)Np * c->LDK);
   A(&c->Xmu, (size_t)N_s * Q); A(&c->Xs, (size_t)N_s * Q); A(&c->dir, (size_t)2 * N_s * Q);
-  A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->U, (size_t)Np * Q); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
+  A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->U, (size_t)Np * Q); A(&c->PU, (size_t)Np * (2 * ((Q + 1) / 2 * 2) + 2)); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
   A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp);
   A(&c->stats, (size_t)Mp * Mp + Mp * Dp + SC_COUNT);
   A(&c->grads, (size_t)M * Q + Q);
@@ -129,7 +129,8 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   // worst case slices x tiles (regime B uses fewer tiles, hence possibly more slices)
   const int Tb = mt * dt;
   const int Sb = std::max(1, std::min(512 / std::max(1, Tb), total_chunks));
-  c->part_doubles = (size_t)std::max((long)(S + 8) * c->n_tiles, (long)(Sb + 8) * Tb) * TILE * TILE;
+  c->part_doubles = (size_t)std::max((long)(S + 16) * c->n_tiles, (long)(Sb + 16) * Tb) * TILE * TILE;
+  if (c->part_doubles < (size_t)600 * TILE * TILE) c->part_doubles = (size_t)600 * TILE * TILE;
   A(&c->part, c->part_doubles);
   c->kl_blocks = blocks_for(Np);
   A(&c->klpart, (size_t)c->kl_blocks + 8192);
@@ -158,7 +159,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (!c) return GP_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->U, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
+  double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->U, c->PU, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
                     c->HZp, c->gXmu, c->gXs, c->gapart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->lnc2h, c->DZ2,
@@ -166,6 +167,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);
   if (c->ptiles) (void)hipFree(c->ptiles);
+  if (c->bmap) (void)hipFree(c->bmap);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return GP_OK;

@@ -64,6 +64,7 @@ struct gp_ctx {
   double* mu = nullptr;       // [Np][Q] trial means
   double* S = nullptr;        // [Np][Q] trial variances (actual)
   double* U = nullptr;        // [Np][Q] u = alpha / (alpha S + 1)
+  double* PU = nullptr;       // [Np][2*QP+2] packed [mu | u | ln c1] rows for psi1_kernel (QP = Q rounded up to 2, <= 16)
   double* lnc1 = nullptr;     // [Np] ln(sf2) - 1/2 sum ln(a S + 1)
   double* Xa = nullptr;       // [Np][CXp] per-point features for the n-contraction
   double* Z = nullptr;        // [Mp][Q] (rows >= M zero)
@@ -77,6 +78,8 @@ struct gp_ctx {
   size_t part_doubles = 0;
   int* tiles = nullptr;       // phase-1 tile table (int2)
   int n_tiles = 0, p1_slices = 0, p1_cps = 0;
+  int* bmap = nullptr;        // phase-1 block -> (slice, tile type) placement table
+  int bmap_T = -1, bmap_S = -1, bmap_blocks = 0;
   double* klpart = nullptr;   // [blocks] partial KL sums
   int kl_blocks = 0;
   double sumYY = 0;           // host copy, computed at upload

@@ -93,42 +93,67 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 
 // ------------------------------------------------------------------------------------------------ Psi1
 // Kaug[n][m] = exp(ln c1_n - 1/2 sum_q u_nq (mu_nq - z_mq)^2), u = alpha/(alpha S + 1)   (kernel_exp.py:80)
-// block: 64 rows x 128 columns; thread: one column, 32 rows; z_m lives in registers for Q <= 16; the row index is
-// wave-uniform (readfirstlane) so mu / u / ln c1 arrive through scalar loads and feed the FMAs as SGPR operands.
-template <int QT>
-__global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ mu, const double* __restrict__ U,
-                                                   const double* __restrict__ lnc1, const double* __restrict__ Z,
-                                                   double* __restrict__ Kaug, long N, long Np, int M, int Q, long ld) {
+// block: 64 rows x 128 columns; thread: one column, 32 rows; z_m lives in registers (QP = Q rounded up to 2, zero
+// padded); the row index is wave-uniform (readfirstlane), so the packed per-point row PU[n] = [mu_n | u_n | ln c1_n]
+// arrives through wide scalar loads and feeds the FMAs as SGPR operands; no guards in the q loop (padding has u = 0).
+template <int QP>
+__global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
+                                                   long N, long Np, int M, int Q, long ld) {
   const int col = blockIdx.x * 128 + (threadIdx.x & 127);
   const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
   const long row0 = blockIdx.y * 64L + half * 32;
-  double z[QT > 0 ? QT : 1];
-#pragma unroll
-  for (int q = 0; q < QT; ++q) z[q] = (q < Q && col < M) ? Z[(long)col * Q + q] : 0.0;
   const bool colok = col < M;
-#pragma unroll 4
+  double z[QP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) z[q] = (q < Q && colok) ? Z[(long)col * Q + q] : 0.0;
+  constexpr int W = 2 * QP + 2;   // row width of PU (doubles), a multiple of 2
+#pragma unroll 2
+  for (int r = 0; r < 32; ++r) {
+    const long n = row0 + r;       // Np is a multiple of 64: always in range
+    const double* row = PU + n * W;
+    double e = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const double d = row[q] - z[q];
+      e = fma(row[QP + q] * d, d, e);
+    }
+    const double v = (n < N && colok) ? exp(row[2 * QP] - 0.5 * e) : 0.0;
+    Kaug[n * ld + col] = v;
+  }
+}
+
+// generic fallback (any Q): operands from global memory
+__global__ void __launch_bounds__(256) psi1_generic_kernel(const double* __restrict__ mu, const double* __restrict__ U,
+                                                           const double* __restrict__ lnc1, const double* __restrict__ Z,
+                                                           double* __restrict__ Kaug, long N, long Np, int M, int Q, long ld) {
+  const int col = blockIdx.x * 128 + (threadIdx.x & 127);
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+  const long row0 = blockIdx.y * 64L + half * 32;
+  const bool colok = col < M;
   for (int r = 0; r < 32; ++r) {
     const long n = row0 + r;
-    if (n >= Np) break;
-    const double* mrow = mu + n * Q;
-    const double* urow = U + n * Q;
     double e = 0.0;
-    if (QT > 0) {
-#pragma unroll
-      for (int q = 0; q < QT; ++q) {
-        if (q < Q) {
-          const double d = mrow[q] - z[q];
-          e = fma(urow[q] * d, d, e);
-        }
-      }
-    } else {
-      for (int q = 0; q < Q; ++q) {
-        const double d = mrow[q] - (colok ? Z[(long)col * Q + q] : 0.0);
-        e = fma(urow[q] * d, d, e);
-      }
+    for (int q = 0; q < Q; ++q) {
+      const double d = mu[n * Q + q] - (colok ? Z[(long)col * Q + q] : 0.0);
+      e = fma(U[n * Q + q] * d, d, e);
     }
-    const double v = (n < N && colok) ? exp(lnc1[n] - 0.5 * e) : 0.0;
-    Kaug[n * ld + col] = v;
+    Kaug[n * ld + col] = (n < N && colok) ? exp(lnc1[n] - 0.5 * e) : 0.0;
+  }
+}
+
+// PU[n] = [mu_n (QP) | u_n (QP) | ln c1_n | 0]
+__global__ void __launch_bounds__(256) pack_pu_kernel(const double* __restrict__ mu, const double* __restrict__ U, const double* __restrict__ lnc1,
+                                                      long Np, int Q, int QP, double* __restrict__ PU) {
+  const int W = 2 * QP + 2;
+  const long total = Np * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long n = i / W;
+    const int c = (int)(i - n * W);
+    double v = 0.0;
+    if (c < QP) { if (c < Q) v = mu[n * Q + c]; }
+    else if (c < 2 * QP) { if (c - QP < Q) v = U[n * Q + c - QP]; }
+    else if (c == 2 * QP) v = lnc1[n];
+    PU[i] = v;
   }
 }
 
@@ -138,13 +163,12 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ mu
 // p1_reduce_kernel.  All tile types of one slice sit on one XCD (block b runs on XCD b % 8) so the slice's rows
 // are fetched from HBM once and re-read from that XCD's L2.
 struct P1Args {
-  const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; int psi2_tiles; int dbg;
+  const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; int psi2_tiles; int dbg; const int* bmap;
 };
 
 __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
-  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-  const int slice = xcd + 8 * (i / p.T), type = i % p.T;
-  if (slice >= p.S) return;
+  const int slice = p.bmap[2 * blockIdx.x], type = p.bmap[2 * blockIdx.x + 1];   // host-built placement table
+  if (slice < 0) return;
   const int ti = p.tiles[2 * type], tj = p.tiles[2 * type + 1];
   __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -231,11 +255,10 @@ int run_upload_y(gp_ctx* c, const double* dY) {
   return GP_OK;
 }
 
-template <int QT>
+template <int QP>
 static void launch_psi1(gp_ctx* c) {
-  dim3 grid(c->Mp / 128, (unsigned)((c->Np + 63) / 64));
-  hipLaunchKernelGGL((psi1_kernel<QT>), grid, dim3(256), 0, c->stream, c->mu, c->U, c->lnc1, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M,
-                     c->Q, (long)c->LDK);
+  dim3 grid(c->Mp / 128, (unsigned)(c->Np / 64));
+  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Q, (long)c->LDK);
 }
 
 int run_prep_and_generate(gp_ctx* c) {
@@ -248,10 +271,26 @@ int run_prep_and_generate(gp_ctx* c) {
   hipLaunchKernelGGL(prep_row_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());
   (void)hipEventRecord(c->ev[8], c->stream);
-  if (c->Q <= 4) launch_psi1<4>(c);
-  else if (c->Q <= 10) launch_psi1<10>(c);
-  else if (c->Q <= 16) launch_psi1<16>(c);
-  else launch_psi1<0>(c);
+  const int QP = (c->Q + 1) / 2 * 2;
+  if (QP <= 16) {
+    const long total = c->Np * (2L * QP + 2);
+    hipLaunchKernelGGL(pack_pu_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 16384)), dim3(256), 0, c->stream, c->mu, c->U, c->lnc1,
+                       (long)c->Np, c->Q, QP, c->PU);
+    switch (QP) {
+      case 2: launch_psi1<2>(c); break;
+      case 4: launch_psi1<4>(c); break;
+      case 6: launch_psi1<6>(c); break;
+      case 8: launch_psi1<8>(c); break;
+      case 10: launch_psi1<10>(c); break;
+      case 12: launch_psi1<12>(c); break;
+      case 14: launch_psi1<14>(c); break;
+      default: launch_psi1<16>(c); break;
+    }
+  } else {
+    dim3 grid(c->Mp / 128, (unsigned)(c->Np / 64));
+    hipLaunchKernelGGL(psi1_generic_kernel, grid, dim3(256), 0, c->stream, c->mu, c->U, c->lnc1, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M,
+                       c->Q, (long)c->LDK);
+  }
   (void)hipEventRecord(c->ev[9], c->stream);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -265,15 +304,45 @@ int run_phase1(gp_ctx* c) {
   P1Args p;
   p.Kaug = c->Kaug; p.ld = c->LDK; p.tiles = c->tiles + 2 * first; p.T = T;
   p.total_chunks = (int)(c->Np / KC);
-  // slices: a multiple of 8 (block b runs on XCD b % 8 and a slice lives on one XCD) with at most 64 workgroups per XCD,
-  // so that every workgroup is resident at once (a 65th workgroup on an XCD would wait for a whole first round)
-  int S = 8 * std::max(1, 64 / std::max(T, 1));
-  S = std::max(1, std::min(S, p.total_chunks));
+  // Placement (block b runs on XCD b % 8, 64 resident workgroups per XCD at 2 per CU): every XCD gets L = 64/T whole
+  // slices (all T tile types of a slice share the XCD's L2, so the slice's rows are fetched from HBM once); the 64 - L*T
+  // left-over slots per XCD are pooled into "shared" slices whose tile types are spread over neighbouring XCDs.  All
+  // workgroups are resident at once -- a 65th workgroup on an XCD would wait for a whole first round.
+  const int L = 64 / std::max(T, 1);
+  const int left = 64 - L * T;
+  const int n_shared = (T <= 64) ? (8 * left) / T : std::max(1, 512 / T);
+  int S = std::max(1, std::min(8 * L + n_shared, p.total_chunks));
   p.cps = (p.total_chunks + S - 1) / S;
   S = (p.total_chunks + p.cps - 1) / p.cps;
   p.S = S; p.part = c->part; p.psi2_tiles = 0;
   { const char* e = getenv("GP_P1_DBG"); p.dbg = e ? atoi(e) : 0; }
-  const int blocks = 8 * ((S + 7) / 8) * T;
+  if (c->bmap_T != T || c->bmap_S != S) {
+    const int per_xcd = (T <= 64) ? 64 : (S * T + 7) / 8;
+    std::vector<int> slot(8 * per_xcd * 2, -1);     // [xcd][j] -> (slice, type)
+    std::vector<int> fill(8, 0);
+    int sl = 0;
+    for (int x = 0; x < 8 && T <= 64; ++x)
+      for (int l = 0; l < L && sl < S; ++l, ++sl)
+        for (int t = 0; t < T; ++t) { const int j = fill[x]++; slot[(x * per_xcd + j) * 2] = sl; slot[(x * per_xcd + j) * 2 + 1] = t; }
+    int x = 0;
+    for (; sl < S; ++sl)
+      for (int t = 0; t < T; ++t) {
+        while (fill[x] >= per_xcd) x = (x + 1) & 7;
+        const int j = fill[x]++;
+        slot[(x * per_xcd + j) * 2] = sl; slot[(x * per_xcd + j) * 2 + 1] = t;
+        if (fill[x] >= per_xcd || (T <= 64 && fill[x] - L * T >= (left + 1) / 2 * 2 && false)) x = (x + 1) & 7;
+      }
+    std::vector<int> bm(8 * per_xcd * 2);
+    for (int j = 0; j < per_xcd; ++j)
+      for (int xx = 0; xx < 8; ++xx) { bm[(j * 8 + xx) * 2] = slot[(xx * per_xcd + j) * 2]; bm[(j * 8 + xx) * 2 + 1] = slot[(xx * per_xcd + j) * 2 + 1]; }
+    if (c->bmap) (void)hipFree(c->bmap);
+    GP_HIP(c, hipMalloc((void**)&c->bmap, bm.size() * sizeof(int)));
+    GP_HIP(c, hipMemcpyAsync(c->bmap, bm.data(), bm.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+    c->bmap_T = T; c->bmap_S = S; c->bmap_blocks = 8 * per_xcd;
+  }
+  p.bmap = c->bmap;
+  const int blocks = c->bmap_blocks;
   (void)hipEventRecord(c->ev[10], c->stream);
   hipLaunchKernelGGL(p1_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
   (void)hipEventRecord(c->ev[11], c->stream);
@@ -452,6 +521,10 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
 #pragma unroll
     for (int bc = 0; bc < NRB; ++bc) r[am][bc] = 0.0;
   const int crow = lane >> 2, ccg = lane & 3;                     // coalesced slab load: row, 16-column group
+  if (p.dbg & 12) {
+    const bool late = (p.dbg & 4) ? (((blockIdx.x >> 3) & 32) != 0) : (((blockIdx.x >> 3) & 1) != 0);
+    if (late) { const long t_end = wall_clock64() + 10000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64); }
+  }
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
@@ -468,11 +541,12 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
         tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
         tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
       }
-      mma_chunk_sb<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+      if (!(p.dbg & 2)) mma_chunk_sb<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
       dma_wait();
       __syncthreads();
     }
     mfma_drain(acc.v[3][15]);
+    if (p.dbg & 1) { __syncthreads(); continue; }
     // ---- epilogue: all staging buffers are free now
     {
       const double2* src = reinterpret_cast<const double2*>(p.Xa + n0 * p.CXp);
@@ -489,7 +563,7 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
     for (int ar = 0; ar < 4; ++ar) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(slab + crow * SLAB_LD + 16 * ccg + 2 * i) = kv[i];
-      if (ar < 3) {
+      if (ar < 3 && !(p.dbg & 64)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const double2*>(kbase + (long)(16 * (ar + 1)) * p.ld + 2 * i);
       }
@@ -506,10 +580,12 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
         for (int am = 0; am < 4; ++am) a[am] = slab[(4 * k4 + lk) * SLAB_LD + 16 * am + lr];
 #pragma unroll
         for (int bc = 0; bc < NRB; ++bc) b[bc] = xrow[(4 * k4 + lk) * p.CXp + 4 * bc];   // CXp == 4 * NRB
+        if (!(p.dbg & 32)) {
 #pragma unroll
         for (int am = 0; am < 4; ++am)
 #pragma unroll
           for (int bc = 0; bc < NRB; ++bc) mfma444_acc(r[am][bc], a[am], b[bc]);
+        }
       }
     }
     mfma_drain(r[3][NRB - 1]);   // hipcc may spill r[] around the k-loop: its MFMAs must have retired first
@@ -604,7 +680,7 @@ int run_phase2(gp_ctx* c) {
   S = (p.ntiles + p.tps - 1) / p.tps;
   p.S = S;
   p.kbeg = c->regime_A ? 0 : c->Mp / KC;
-  p.kend = c->LDK / KC;
+  p.kend = (c->Mp + (int)round_up(c->D, KC)) / KC;   // chunks beyond the last real Y column are all zero
   { const char* e = getenv("GP_P2_DBG"); p.dbg = e ? atoi(e) : 0; }
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
   (void)hipEventRecord(c->ev[12], c->stream);

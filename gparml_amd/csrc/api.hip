@@ -374,6 +374,14 @@ extern "C" int gp_phase2(gp_ctx* c, int want_embedding_grads) {
   }
   GP_TRY(run_phase2(c));
   if (!c->regime_A) GP_TRY(run_phase2_b(c));
+  if (c->want_emb && c->xs_raw) {
+    // the .grad_latest vector of this evaluation, resident for the optimiser's dot products
+    const long nq = (long)c->N * c->Q;
+    hipLaunchKernelGGL(grad_latest_kernel, dim3(blocks_for(nq)), dim3(256), 0, c->stream, c->gXmu, c->gXs, c->Xs, c->dir, (long)c->N, c->Q, c->step,
+                       1, c->have_dir ? 1 : 0, c->g_latest);
+    GP_HIP(c, hipGetLastError());
+    c->have_glatest = true;
+  }
   GP_HIP(c, hipEventRecord(c->ev[6], c->stream));
   c->state = 3;
   return GP_OK;
@@ -501,7 +509,98 @@ extern "C" int gp_finish(gp_ctx* c, double* F, double* grad_Z, double* grad_sf2,
   }
   return GP_OK;
 }
-extern "C" int gp_cg_set_grads(gp_ctx* c) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }
-extern "C" int gp_cg_dots(gp_ctx* c, double*) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }
-extern "C" int gp_cg_max_d(gp_ctx* c, double, double*) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }
-extern "C" int gp_cg_update(gp_ctx* c, int, double) { return c ? fail(c, GP_ERR_UNSUPPORTED, "cg not built yet") : GP_ERR_BAD_ARG; }
+// ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243) --------------------------------------------------------
+// which: 0 d = -g_new (reset_d :160-173) | 1 d = a*d - g_new (update_d :175-189) | 2 X += a*d (update_X :191-214)
+//        3 g_old = g_new (:216-229) | 4 g_new = g_latest (:231-243) | 5 set_grads: g_new = g_old = g_latest, d = -g_latest (:29-55)
+__global__ void cg_update_kernel(int which, double a, long nq, double* __restrict__ d, double* __restrict__ gnew, double* __restrict__ gold,
+                                 const double* __restrict__ glatest, double* __restrict__ Xmu, double* __restrict__ Xs) {
+  const long n2 = 2 * nq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256L) {
+    switch (which) {
+      case 0: d[i] = -gnew[i]; break;
+      case 1: d[i] = a * d[i] - gnew[i]; break;
+      case 2: if (i < nq) Xmu[i] += a * d[i]; else Xs[i - nq] += a * d[i]; break;
+      case 3: gold[i] = gnew[i]; break;
+      case 4: gnew[i] = glatest[i]; break;
+      default: { const double g = glatest[i]; gnew[i] = g; gold[i] = g; d[i] = -g; } break;
+    }
+  }
+}
+// out[0..4] += (g_new.d, d.d, d.(g_latest - g_new), g_new.g_new, g_new.g_old); out[5] = max(out[5], max |d|)
+__global__ void __launch_bounds__(256) cg_dots_kernel(long n2, const double* __restrict__ d, const double* __restrict__ gnew,
+                                                      const double* __restrict__ gold, const double* __restrict__ glatest, double* part) {
+  __shared__ double red[6][256];
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256L) {
+    const double di = d[i], gn = gnew[i];
+    s[0] += gn * di; s[1] += di * di; s[2] += di * (glatest[i] - gn); s[3] += gn * gn; s[4] += gn * gold[i];
+    s[5] = fmax(s[5], fabs(di));
+  }
+  for (int k = 0; k < 6; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+      red[5][threadIdx.x] = fmax(red[5][threadIdx.x], red[5][threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+static int cg_ready(gp_ctx* c, const char* what) {
+  if (!c->have_data) return fail(c, GP_ERR_STATE, "%s: no shard data", what);
+  if (!c->xs_raw) return fail(c, GP_ERR_STATE, "%s: the resident CG vectors exist only for free embeddings (raw variances)", what);
+  return GP_OK;
+}
+
+extern "C" int gp_cg_update(gp_ctx* c, int which, double a) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (which < 0 || which > 5) return fail(c, GP_ERR_BAD_ARG, "gp_cg_update: which must be 0..5");
+  GP_TRY(cg_ready(c, "gp_cg_update"));
+  if ((which == 4 || which == 5) && !c->have_glatest) return fail(c, GP_ERR_STATE, "gp_cg_update: no grad_latest yet (gp_phase2(ctx, 1) first)");
+  GP_HIP(c, hipSetDevice(c->device));
+  const long nq = (long)c->N * c->Q;
+  hipLaunchKernelGGL(cg_update_kernel, dim3(blocks_for(2 * nq)), dim3(256), 0, c->stream, which, a, nq, c->dir, c->g_new, c->g_old, c->g_latest,
+                     c->Xmu, c->Xs);
+  GP_HIP(c, hipGetLastError());
+  if (which == 0 || which == 1 || which == 5) c->have_dir = true;
+  if (which == 2) c->state = 0;   // the embeddings moved: statistics are stale
+  return GP_OK;
+}
+
+extern "C" int gp_cg_set_grads(gp_ctx* c) { return gp_cg_update(c, 5, 0.0); }
+
+static int cg_reduce(gp_ctx* c, double* out6) {
+  const long n2 = 2L * c->N * c->Q;
+  const int nb = std::min(blocks_for(n2), 1024);
+  double* part = c->klpart + c->kl_blocks;   // spare tail (8192 doubles)
+  hipLaunchKernelGGL(cg_dots_kernel, dim3(nb), dim3(256), 0, c->stream, n2, c->dir, c->g_new, c->g_old, c->g_latest, part);
+  std::vector<double> h((size_t)nb * 6);
+  GP_HIP(c, hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 6; ++k) out6[k] = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    for (int k = 0; k < 5; ++k) out6[k] += h[(size_t)b * 6 + k];
+    out6[5] = std::max(out6[5], h[(size_t)b * 6 + 5]);
+  }
+  return GP_OK;
+}
+
+extern "C" int gp_cg_dots(gp_ctx* c, double* out6) {
+  if (!c || !out6) return GP_ERR_BAD_ARG;
+  GP_TRY(cg_ready(c, "gp_cg_dots"));
+  if (!c->have_dir) return fail(c, GP_ERR_STATE, "gp_cg_dots: no search direction (gp_cg_set_grads first)");
+  GP_HIP(c, hipSetDevice(c->device));
+  return cg_reduce(c, out6);
+}
+
+extern "C" int gp_cg_max_d(gp_ctx* c, double alpha, double* out) {
+  if (!c || !out) return GP_ERR_BAD_ARG;
+  GP_TRY(cg_ready(c, "gp_cg_max_d"));
+  GP_HIP(c, hipSetDevice(c->device));
+  double o[6];
+  GP_TRY(cg_reduce(c, o));
+  *out = std::fabs(alpha) * o[5];
+  return GP_OK;
+}

@@ -52,7 +52,7 @@ struct gp_ctx {
   double sf2 = 1, beta = 1, step = 0;
   bool regime_A = true;   // every variance exactly zero (fixed embeddings)
   bool xs_raw = false;    // X_S stored in softplus-inverse space
-  bool have_data = false, have_globals = false, have_dir = false;
+  bool have_data = false, have_globals = false, have_dir = false, have_glatest = false;
   int state = 0;          // 0 nothing, 1 phase1 done, 2 stats final (global step done), 3 phase2 done
   bool want_emb = false;
 

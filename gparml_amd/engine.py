@@ -99,6 +99,21 @@ class ShardEngine(object):
         """dst (self) += src or dst = src for the packed statistics / gradient-sum buffers (same device)."""
         self._ck(self.lib.gp_buffer_combine(self.h, src.h, 0 if which == 'stats' else 1, 0 if op == 'add' else 1), 'gp_buffer_combine')
 
+    # ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243) ----------------------------------
+    CG_RESET_D, CG_UPDATE_D, CG_UPDATE_X, CG_GRAD_OLD, CG_GRAD_NEW, CG_SET_GRADS = range(6)
+
+    def cg_set_grads(self):
+        self._ck(self.lib.gp_cg_set_grads(self.h), 'gp_cg_set_grads')
+
+    def cg_dots(self):
+        """local sums [mu, kappa, theta, |g_new|^2, g_new.g_old, max|d|]"""
+        out = np.zeros(6)
+        self._ck(self.lib.gp_cg_dots(self.h, out.ctypes.data_as(_lib._dp)), 'gp_cg_dots')
+        return out
+
+    def cg_update(self, which, a=0.0):
+        self._ck(self.lib.gp_cg_update(self.h, int(which), float(a)), 'gp_cg_update')
+
     def scale_stats(self, factor):
         self._ck(self.lib.gp_scale_stats(self.h, float(factor)), 'gp_scale_stats')
 

@@ -131,11 +131,16 @@ int gp_last_timings(gp_ctx* ctx, double* out8);
 int gp_grad_from_parts(gp_ctx* ctx, int which, const double* dF_dKmm, const double* dKmm_dX, const double* dF_dC, const double* dC_dX,
                        const double* dF_dPsi2, const double* dPsi2_dX, double* out);
 
-/* ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243), "next" row 8(f)-1 ------------ */
-int gp_cg_set_grads(gp_ctx* ctx);                              /* embeddings_set_grads        :29-55   */
-int gp_cg_dots(gp_ctx* ctx, double* out6);                     /* mu,kappa,theta,|g|^2,gamma  :59-140  */
-int gp_cg_max_d(gp_ctx* ctx, double alpha, double* out);       /* max |alpha*d|               :142-155 */
-int gp_cg_update(gp_ctx* ctx, int which, double a);            /* reset_d/update_d/update_X/... :160-243 */
+/* ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243), SURVEY.md section 8(f)-1 ----------------------------
+ * grad_latest / grad_new / grad_old / d are (2,N_s,Q) device arrays; gp_phase2(ctx,1) refreshes grad_latest. */
+int gp_cg_set_grads(gp_ctx* ctx);                              /* embeddings_set_grads :29-55: new = old = latest, d = -latest */
+/* out6 = [mu = new.d (:59-74), kappa = d.d (:76-90), theta = d.(latest-new) (:92-110), |new|^2 (:112-126),
+ *         new.old (:128-140; the caller forms Gamma), max|d|] -- local sums, the host all-reduces them across shards */
+int gp_cg_dots(gp_ctx* ctx, double* out6);
+int gp_cg_max_d(gp_ctx* ctx, double alpha, double* out);       /* max |alpha*d| :142-155 */
+/* which: 0 reset_d :160-173 | 1 update_d(a=Gamma) :175-189 | 2 update_X(a=alpha) :191-214 | 3 update_grad_old :216-229 |
+ *        4 update_grad_new :231-243 | 5 set_grads */
+int gp_cg_update(gp_ctx* ctx, int which, double a);
 
 /* ---- test hooks (used by tests/ only) --------------------------------------------------------- */
 /* C = alpha*op(A)op(B) + beta*C through the library's FP64 MFMA GEMM core; A (m,k) or (k,m) if ta,

@@ -118,6 +118,7 @@ struct gp_ctx {
   double* DZ2 = nullptr;      // [M][M][Q] (z_mq - z_m'q)^2
   double* Gpart = nullptr;    // [pb_blocks][M][Q] per-block grad_Z partials of the psi2 part
   double* gapart2 = nullptr;  // [pb_blocks][Q]
+  double* pp = nullptr;       // [Np][3Q+1] per-point running sums sr, zr, z2r, zt of the psi2 rows kernel
   int pb_blocks = 0;
   int* ptiles = nullptr;      // upper-triangular 16x16 tile table for the psi2 pair kernel
   int n_ptiles = 0;

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) b_tables_kernel(const double* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ mu, const double* __restrict__ Wn,
+__global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ mu, const double* __restrict__ Wn, const double* __restrict__ Vn,
                                                     const double* __restrict__ lnc2h, const double* __restrict__ Z, long N, long Np,
                                                     int M, int Mp, int Q, double* __restrict__ LE, double* __restrict__ LET) {
   // block: 16 rows (n) x 16 cols (m) tile computed once, written in both layouts through LDS
@@ -48,7 +48,12 @@ __global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ mu
     e = -1e300;   // exp() of a padded entry is exactly 0
   }
   LE[n * Mp + m] = e;
-  tile[ty][tx] = e;
+  // LEA = LE + sum_q V_nq z_mq^2: with it the pair exponent is LEA_nm + LEA_nm' - 2 sum_q V_nq z_mq z_m'q
+  double ea = e;
+  if (n < N && m < M) {
+    for (int q = 0; q < Q; ++q) { const double z = Z[(long)m * Q + q]; ea = fma(Vn[n * Q + q] * z, z, ea); }
+  }
+  tile[ty][tx] = ea;
   __syncthreads();
   const long n2 = blockIdx.y * 16L + tx;
   const int m2 = blockIdx.x * 16 + ty;
@@ -128,109 +133,127 @@ __global__ void fill_kernel(double* x, long n, double v) {
 //   grad_alpha += -1/4 quad/d2^2 - (S/d2) sr ; grad_X_mu += -w (2 mu sr - 2 zr) ; grad_X_S += 1/2 w^2 quad - w sr
 struct PB2Args {
   const double* LET; const double* Vn; const double* Wn; const double* mu; const double* S; const double* DZ2; const double* Z;
-  const double* Bbar; const double* alpha; double* Gpart; double* gapart2; double* gmu; double* gS;
+  const double* Bbar; const double* alpha; double* Gpart; double* gapart2; double* gmu; double* gS; double* pp;
   long N, Np; int M, Mp, Q, groups_per_block;
 };
 
+constexpr int MC = 4;   // inducing rows per pass: one LEA[m'][n] load and one uniform z_m' vector serve MC pair terms
+
 template <int QT>
-__global__ void __launch_bounds__(256) psi2_rows_kernel(PB2Args a) {
-  __shared__ double red[4][QT > 0 ? QT : 1];
-  __shared__ double redq[256];
+__global__ void __launch_bounds__(256, 2) psi2_rows_kernel(PB2Args a) {
+  // LET holds LEA (m-major): exponent(n; m, m') = LEA[m][n] + LEA[m'][n] + sum_q p_mq z_m'q with p_mq = -2 V_nq z_mq.
+  // Per point the running sums sr, zr_q, z2r_q, zt_q live in a.pp (global, touched once per MC rows), so the inner loop
+  // keeps only p[MC][Q], t[MC][Q] and r[MC] in registers.
+  __shared__ double red[4][MC][QT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;
-  double ga_acc[QT > 0 ? QT : 1];
-#pragma unroll
-  for (int q = 0; q < QT; ++q) ga_acc[q] = 0.0;
+  const int PW = 3 * a.Q + 1;
   for (int grp = 0; grp < a.groups_per_block; ++grp) {
     const long n = ((long)blockIdx.x * a.groups_per_block + grp) * 256 + tid;
     const bool live = n < a.N;
     const long nn = live ? n : 0;
-    double mu[QT > 0 ? QT : 1], w[QT > 0 ? QT : 1], v[QT > 0 ? QT : 1];
-    double zr[QT > 0 ? QT : 1], z2r[QT > 0 ? QT : 1], zt[QT > 0 ? QT : 1];
-    double sr = 0.0;
+    double* ppn = a.pp + nn * PW;
+    if (live) for (int k = 0; k < PW; ++k) ppn[k] = 0.0;
+    const double* lcol = a.LET + nn;
+    for (int m0 = 0; m0 < a.M; m0 += MC) {
+      double p[MC][QT], t[MC][QT], r[MC], lem[MC];
 #pragma unroll
-    for (int q = 0; q < QT; ++q) {
-      mu[q] = (q < a.Q) ? a.mu[nn * a.Q + q] : 0.0;
-      w[q] = (q < a.Q) ? a.Wn[nn * a.Q + q] : 0.0;
-      v[q] = (q < a.Q) ? a.Vn[nn * a.Q + q] : 0.0;
-      zr[q] = 0.0; z2r[q] = 0.0; zt[q] = 0.0;
-    }
-    for (int m = 0; m < a.M; ++m) {
-      const double lem = live ? a.LET[(long)m * a.Np + nn] : -1e300;
-      double r = 0.0;
-      double t[QT > 0 ? QT : 1];
+      for (int k = 0; k < MC; ++k) {
+        const double* zm = a.Z + (long)(m0 + k) * a.Q;               // wave-uniform (rows >= M are zero)
+        lem[k] = (live && m0 + k < a.M) ? lcol[(long)(m0 + k) * a.Np] : -1e300;
+        r[k] = 0.0;
 #pragma unroll
-      for (int q = 0; q < QT; ++q) t[q] = 0.0;
-      const double* brow = a.Bbar + (long)m * a.Mp;
+        for (int q = 0; q < QT; ++q) { p[k][q] = (q < a.Q) ? -2.0 * a.Vn[nn * a.Q + q] * zm[q] : 0.0; t[k][q] = 0.0; }
+      }
+      const double* brow = a.Bbar + (long)m0 * a.Mp;                 // wave-uniform, MC consecutive rows
+#pragma unroll 2
       for (int m2 = 0; m2 < a.M; ++m2) {
-        double e = lem + a.LET[(long)m2 * a.Np + nn];
-        const double* dz = a.DZ2 + ((long)m * a.M + m2) * a.Q;   // wave-uniform
-        const double* z2 = a.Z + (long)m2 * a.Q;                   // wave-uniform
+        const double* z2 = a.Z + (long)m2 * a.Q;                     // wave-uniform
+        const double l2 = lcol[(long)m2 * a.Np];
+        double zz[QT];
 #pragma unroll
-        for (int q = 0; q < QT; ++q) if (q < a.Q) e = fma(v[q], dz[q], e);
-        const double T = brow[m2] * exp(e);
-        r += T;
+        for (int q = 0; q < QT; ++q) zz[q] = (q < a.Q) ? z2[q] : 0.0;
 #pragma unroll
-        for (int q = 0; q < QT; ++q) if (q < a.Q) t[q] = fma(T, z2[q], t[q]);
-      }
-      if (!live) r = 0.0;
-      sr += r;
-      const double* zm = a.Z + (long)m * a.Q;
+        for (int k = 0; k < MC; ++k) {
+          double e = lem[k] + l2;
 #pragma unroll
-      for (int q = 0; q < QT; ++q) {
-        if (q < a.Q) {
-          const double z = zm[q];
-          const double tq = live ? t[q] : 0.0;
-          zr[q] = fma(z, r, zr[q]);
-          z2r[q] = fma(z * z, r, z2r[q]);
-          zt[q] = fma(z, tq, zt[q]);
-          // grad_Z contribution of this point, reduced over the block
-          double g = -a.alpha[q] * (z * r - tq) + w[q] * (2.0 * mu[q] * r - z * r - tq);
-          for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-          if (lane == 0) red[wave][q] = g;
+          for (int q = 0; q < QT; ++q) e = fma(p[k][q], zz[q], e);
+          const double T = brow[(long)k * a.Mp + m2] * exp(e);
+          r[k] += T;
+#pragma unroll
+          for (int q = 0; q < QT; ++q) t[k][q] = fma(T, zz[q], t[k][q]);
         }
       }
-      __syncthreads();
-      if (tid < a.Q) {
-        const double s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        double* dst = G + (long)m * a.Q + tid;
-        *dst = ((grp == 0) ? 0.0 : *dst) + s;
-      }
-      __syncthreads();
-    }
-    if (live) {
+      // fold the MC rows into the per-point sums and the block-level grad_Z contribution
+      double dsr = 0.0;
 #pragma unroll
-      for (int q = 0; q < QT; ++q) {
-        if (q < a.Q) {
-          const double s = a.S[n * a.Q + q], al = a.alpha[q];
-          const double d2 = 2.0 * al * s + 1.0;
-          const double quad = 4.0 * mu[q] * mu[q] * sr - 8.0 * mu[q] * zr[q] + 2.0 * z2r[q] + 2.0 * zt[q];
-          ga_acc[q] += -0.25 * quad / (d2 * d2) - (s / d2) * sr;
-          a.gmu[n * a.Q + q] += -w[q] * (2.0 * mu[q] * sr - 2.0 * zr[q]);
-          a.gS[n * a.Q + q] += 0.5 * w[q] * w[q] * quad - w[q] * sr;
+      for (int k = 0; k < MC; ++k) {
+        const double* zm = a.Z + (long)(m0 + k) * a.Q;
+        const double rk = live ? r[k] : 0.0;
+        dsr += rk;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+          if (q < a.Q) {
+            const double z = zm[q];
+            const double tq = live ? t[k][q] : 0.0;
+            if (live) {
+              ppn[1 + q] = fma(z, rk, ppn[1 + q]);
+              ppn[1 + a.Q + q] = fma(z * z, rk, ppn[1 + a.Q + q]);
+              ppn[1 + 2 * a.Q + q] = fma(z, tq, ppn[1 + 2 * a.Q + q]);
+            }
+            const double w = a.Wn[nn * a.Q + q], mu = a.mu[nn * a.Q + q];
+            double g = -a.alpha[q] * (z * rk - tq) + w * (2.0 * mu * rk - z * rk - tq);
+            for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+            if (lane == 0) red[wave][k][q] = g;
+          }
         }
       }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < QT; ++q) {
-    if (q < a.Q) {
-      redq[tid] = ga_acc[q];
+      if (live) ppn[0] += dsr;
       __syncthreads();
-      for (int k = 128; k > 0; k >>= 1) { if (tid < k) redq[tid] += redq[tid + k]; __syncthreads(); }
-      if (tid == 0) a.gapart2[(long)blockIdx.x * a.Q + q] = redq[0];
+      if (tid < MC * a.Q) {
+        const int k = tid / a.Q, q = tid - k * a.Q;
+        if (m0 + k < a.M) {
+          const double s = red[0][k][q] + red[1][k][q] + red[2][k][q] + red[3][k][q];
+          double* dst = G + (long)(m0 + k) * a.Q + q;
+          *dst = ((grp == 0) ? 0.0 : *dst) + s;
+        }
+      }
       __syncthreads();
     }
   }
 }
 
+// per-point finish of the psi2 part from the running sums pp[n] = [sr, zr_q, z2r_q, zt_q]
+__global__ void __launch_bounds__(256) psi2_points_finish_kernel(PB2Args a) {
+  __shared__ double redq[256];
+  const int PW = 3 * a.Q + 1;
+  for (int q = 0; q < a.Q; ++q) {
+    double ga = 0.0;
+    for (long n = blockIdx.x * 256L + threadIdx.x; n < a.N; n += (long)gridDim.x * 256L) {
+      const double* ppn = a.pp + n * PW;
+      const double sr = ppn[0], zr = ppn[1 + q], z2r = ppn[1 + a.Q + q], zt = ppn[1 + 2 * a.Q + q];
+      const double s = a.S[n * a.Q + q], al = a.alpha[q], w = a.Wn[n * a.Q + q], mu = a.mu[n * a.Q + q];
+      const double d2 = 2.0 * al * s + 1.0;
+      const double quad = 4.0 * mu * mu * sr - 8.0 * mu * zr + 2.0 * z2r + 2.0 * zt;
+      ga += -0.25 * quad / (d2 * d2) - (s / d2) * sr;
+      a.gmu[n * a.Q + q] += -w * (2.0 * mu * sr - 2.0 * zr);
+      a.gS[n * a.Q + q] += 0.5 * w * w * quad - w * sr;
+    }
+    redq[threadIdx.x] = ga;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) redq[threadIdx.x] += redq[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) a.gapart2[(long)blockIdx.x * a.Q + q] = redq[0];
+    __syncthreads();
+  }
+}
+
 // grads[0:M*Q] += sum_blocks Gpart ; grads[M*Q + q] += sum_blocks gapart2
-__global__ void __launch_bounds__(256) pb2_reduce_kernel(const double* __restrict__ Gpart, const double* __restrict__ gapart2, int nb, long MQ,
-                                                         int Q, double* __restrict__ grads) {
+__global__ void __launch_bounds__(256) pb2_reduce_kernel(const double* __restrict__ Gpart, const double* __restrict__ gapart2, int nb, int nb2,
+                                                         long MQ, int Q, double* __restrict__ grads) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < MQ + Q; i += (long)gridDim.x * 256L) {
     double s = 0.0;
     if (i < MQ) for (int b = 0; b < nb; ++b) s += Gpart[(long)b * MQ + i];
-    else for (int b = 0; b < nb; ++b) s += gapart2[(long)b * Q + (i - MQ)];
+    else for (int b = 0; b < nb2; ++b) s += gapart2[(long)b * Q + (i - MQ)];
     grads[i] += s;
   }
 }
@@ -252,7 +275,7 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   A(&c->DZ2, (size_t)M * M * Q); A(&c->lnc2h, (size_t)Np);
   const long groups = (c->N + 255) / 256;
   c->pb_blocks = (int)std::min<long>(groups, 2048);
-  A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q);
+  A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q); A(&c->pp, (size_t)Np * (3 * Q + 1));
   std::vector<int> t;
   const int Mt = (int)((M + 15) / 16);
   for (int i = 0; i < Mt; ++i) for (int j = i; j < Mt; ++j) { t.push_back(i); t.push_back(j); }
@@ -288,7 +311,7 @@ int run_generate_b(gp_ctx* c) {
   hipLaunchKernelGGL(b_tables_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, c->mu, c->S, c->alpha, (long)c->N, (long)c->Np, c->Q,
                      c->sf2, c->Vn, c->Wn, c->lnc2h);
   dim3 grid(c->Mp / 16, (unsigned)(c->Np / 16));
-  hipLaunchKernelGGL(b_le_kernel, grid, dim3(256), 0, c->stream, c->mu, c->Wn, c->lnc2h, c->Z, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+  hipLaunchKernelGGL(b_le_kernel, grid, dim3(256), 0, c->stream, c->mu, c->Wn, c->Vn, c->lnc2h, c->Z, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
                      c->LE, c->LET);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -322,7 +345,7 @@ int run_phase2_b(gp_ctx* c) {
   if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
   PB2Args a;
   a.LET = c->LET; a.Vn = c->Vn; a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.DZ2 = c->DZ2; a.Z = c->Z; a.Bbar = c->Bbar; a.alpha = c->alpha;
-  a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs;
+  a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
   a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q;
   const long groups = (c->N + 255) / 256;
   a.groups_per_block = (int)((groups + c->pb_blocks - 1) / c->pb_blocks);
@@ -333,9 +356,11 @@ int run_phase2_b(gp_ctx* c) {
   else if (c->Q <= 32) launch_rows<32>(c, a, blocks);
   else launch_rows<64>(c, a, blocks);
   GP_HIP(c, hipGetLastError());
+  hipLaunchKernelGGL(psi2_points_finish_kernel, dim3(c->pb_blocks), dim3(256), 0, c->stream, a);
+  GP_HIP(c, hipGetLastError());
   const long MQ = (long)c->M * c->Q;
   hipLaunchKernelGGL(pb2_reduce_kernel, dim3((unsigned)std::min<long>((MQ + c->Q + 255) / 256, 1024)), dim3(256), 0, c->stream, c->Gpart,
-                     c->gapart2, blocks, MQ, c->Q, c->grads);
+                     c->gapart2, blocks, c->pb_blocks, MQ, c->Q, c->grads);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }

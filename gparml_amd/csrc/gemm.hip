@@ -9,7 +9,8 @@ namespace gp {
 
 template <Layout LA, Layout LB>
 __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
-  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int bz = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
   if (p.tri == 1 && bx > by) return;
   if (p.tri == 2 && bx < by) return;
   __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
@@ -20,11 +21,12 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
   const double* B = p.B + (long)bi * p.sB + (long)bo * p.oB;
   double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
   const long row0 = (long)by * TILE, col0 = (long)bx * TILE;
-  const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda : A + row0;
-  const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb : B + col0;
+  const int nc = p.K / KC / p.splits;          // chunks of this split
+  const long k0 = (long)sp * nc * KC;
+  const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda + k0 : A + row0 + k0 * p.lda;
+  const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb + k0 : B + col0 + k0 * p.ldb;
   const long a_step = (LA == K_CONTIG) ? KC : (long)KC * p.lda;
   const long b_step = (LB == K_CONTIG) ? KC : (long)KC * p.ldb;
-  const int nc = p.K / KC;
 
   Acc acc;
   acc.zero();
@@ -44,6 +46,15 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
     __syncthreads();
   }
   mfma_drain(acc.v[3][15]);
+  if (p.splits > 1) {
+    // raw partial tile, [z][by][bx][split][128*128]
+    double* w = p.ws + ((((long)bz * gridDim.y + by) * gridDim.x + bx) * p.splits + sp) * (TILE * TILE);
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+      for (int bc = 0; bc < 16; ++bc) w[(wrow0 + acc_row(ar, lane)) * TILE + wcol0 + acc_col(bc, lane)] = acc.v[ar][bc];
+    return;
+  }
   if (p.beta != 0.0) {
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar)
@@ -63,12 +74,29 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
   }
 }
 
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int tiles_x, int tiles_y) {
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x, bz = blockIdx.y;
+  if (p.tri == 1 && bx > by) return;
+  if (p.tri == 2 && bx < by) return;
+  const int bi = bz % p.inner, bo = bz / p.inner;
+  double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
+  const double* w = p.ws + (((long)bz * tiles_y + by) * tiles_x + bx) * p.splits * (TILE * TILE);
+  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+    double s = 0.0;
+    for (int sp = 0; sp < p.splits; ++sp) s += w[(long)sp * (TILE * TILE) + e];
+    const long r = (long)by * TILE + (e >> 7), cc = (long)bx * TILE + (e & 127);
+    C[r * p.ldc + cc] = p.alpha * s + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
+  }
+}
+
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p) {
-  dim3 grid(n / TILE, m / TILE, batch), block(256);
+  dim3 grid(n / TILE, m / TILE, batch * p.splits), block(256);
   if (la == K_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<K_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
   else if (la == K_CONTIG && lb == K_CONTIG) hipLaunchKernelGGL((gemm128_kernel<K_CONTIG, K_CONTIG>), grid, block, 0, st, p);
   else if (la == FREE_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, K_CONTIG>), grid, block, 0, st, p);
+  if (p.splits > 1)
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((n / TILE) * (m / TILE), batch), block, 0, st, p, n / TILE, m / TILE);
 }
 
 }  // namespace gp

@@ -25,6 +25,8 @@ struct GemmP {
   int tri;          // 0 all tiles, 1 only tiles with row-tile >= col-tile (lower), 2 only upper
   int inner = 1 << 30;  // blockIdx.z = i + inner * o: inner index i uses sA/sB/sC, outer index o uses oA/oB/oC
   long oA = 0, oB = 0, oC = 0;
+  int splits = 1;       // split-k: partial tiles go to ws, gemm_splitk_reduce applies alpha/beta (small grids only)
+  double* ws = nullptr;
 };
 // m, n multiples of TILE; la/lb: Layout of A (free index = rows of C) and B (free index = cols of C)
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p);
@@ -151,7 +153,8 @@ int compat_build(gp_ctx* c, int which, double** out, long* count);
 // linalg.hip
 int run_global_step(gp_ctx* c);
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,
-                          double* Twork /*[batch][128][Mp]*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/);
+                          double* Twork /*[batch][128][Mp]*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/,
+                          double* splitk_ws /*may be NULL*/);
 }  // namespace gp
 
 #define GP_HIP(ctx, call)                                                                         \

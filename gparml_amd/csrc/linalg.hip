@@ -13,35 +13,95 @@ namespace gp {
 constexpr int NB = 128;  // panel width = GEMM tile
 
 // ---------------------------------------------------------------------------------------------- diagonal panels
-// Cholesky of the 128x128 diagonal block j of each matrix in the batch, in LDS (128 KB + one column).
+// Cholesky of the 128x128 diagonal block j of each matrix in the batch.  1024 threads; thread (ti,tj) keeps the 4x4
+// sub-block (rows 4ti.., cols 4tj..) in registers.  For every 4-column panel: the owner of the diagonal 4x4 factors it,
+// the threads below it solve their 4x4 against it, then everybody applies the rank-4 update from the panel staged in
+// LDS -- two barriers per panel, 64 in total (the element-wise variant needed 256 and was 6x slower).
 __global__ void __launch_bounds__(1024) potrf_diag_kernel(double* A, long ld, long bstride, int j, double* fail) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* a = sm;
-  double* col = sm + NB * NB;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ double panel2[2][NB][5];   // double-buffered by panel parity: step 3 of panel b overlaps step 1 of panel b+1
+  __shared__ double Lbb[4][4];
+  const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
   double* blk = A + (long)blockIdx.x * bstride + ((long)j * NB) * ld + (long)j * NB;
-  for (int idx = tid; idx < NB * NB; idx += 1024) a[idx] = blk[(long)(idx >> 7) * ld + (idx & 127)];
-  __syncthreads();
-  for (int jj = 0; jj < NB; ++jj) {
-    double d2 = a[jj * NB + jj];
-    if (!(d2 > 0.0) || !(d2 < 1e300)) {
-      if (tid == 0) fail[blockIdx.x] = 1.0;
-      d2 = 1.0;
+  double a[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[r][c] = (ti >= tj) ? blk[(long)(4 * ti + r) * ld + 4 * tj + c] : 0.0;
+  bool bad = false;
+  for (int bj = 0; bj < 32; ++bj) {
+    double (*panel)[5] = panel2[bj & 1];
+    if (ti == bj && tj == bj) {
+      // unblocked 4x4 Cholesky in registers (lower); reciprocals of the diagonal go to LDS so that the solves below
+      // multiply instead of divide (an f64 division is ~30 instructions on the critical path of every panel)
+      double inv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double d2 = a[c][c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < c) d2 -= a[c][k] * a[c][k];
+        if (!(d2 > 0.0) || !(d2 < 1e300)) { bad = true; d2 = 1.0; }
+        const double d = sqrt(d2);
+        inv[c] = 1.0 / d;
+        a[c][c] = d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r > c) {
+            double v = a[r][c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < c) v -= a[r][k] * a[c][k];
+            a[r][c] = v * inv[c];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double v = (c <= r) ? a[r][c] : 0.0;
+          a[r][c] = v;
+          Lbb[r][c] = (c == r) ? inv[c] : v;      // diagonal slot holds 1 / L_cc
+          panel[4 * ti + r][c] = v;
+        }
+      if (bad) fail[blockIdx.x] = 1.0;
     }
-    const double d = sqrt(d2), inv = 1.0 / d;
-    if (tid >= jj && tid < NB) col[tid] = (tid == jj) ? d : a[tid * NB + jj] * inv;
     __syncthreads();
-    if (tid >= jj && tid < NB) a[tid * NB + jj] = col[tid];
-    for (int i = jj + 1 + w; i < NB; i += 16) {
-      const double ci = col[i];
-      for (int k = jj + 1 + lane; k <= i; k += 64) a[i * NB + k] -= ci * col[k];
+    if (tj == bj && ti > bj) {
+      // X = A * Lbb^-T  (row by row forward substitution)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = a[r][c];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < c) v -= a[r][k] * Lbb[c][k];
+          a[r][c] = v * Lbb[c][c];                 // Lbb diagonal = reciprocal
+          panel[4 * ti + r][c] = a[r][c];
+        }
+      }
     }
     __syncthreads();
+    if (tj > bj && ti >= tj) {
+      double pr[4][4], pc[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pr[r][k] = panel[4 * ti + r][k]; pc[r][k] = panel[4 * tj + r][k]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[r][c] = fma(-pr[r][k], pc[c][k], a[r][c]);
+    }
+    // the next panel's writes to Lbb / panel happen after the next barrier pair: no extra barrier needed here
   }
-  for (int idx = tid; idx < NB * NB; idx += 1024) {
-    const int r = idx >> 7, c = idx & 127;
-    blk[(long)r * ld + c] = (c <= r) ? a[idx] : 0.0;
-  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int R = 4 * ti + r, C = 4 * tj + c;
+      blk[(long)R * ld + C] = (C <= R) ? a[r][c] : 0.0;
+    }
 }
 
 // inverse of the lower-triangular 128x128 diagonal block j by recursive doubling:
@@ -104,17 +164,16 @@ static bool g_attr_set = false;
 
 // A: [batch][Mp][Mp] SPD in, lower Cholesky factor out (upper zeroed); Linv: L^-1; Inv: A^-1; Twork: [batch][128][Mp]
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A, double* Linv, double* Inv, double* Twork,
-                          double* logdet2, double* fail_flag) {
+                          double* logdet2, double* fail_flag, double* splitk_ws) {
   const int nt = Mp / NB;
   const long ld = Mp, bs = (long)Mp * Mp;
   if (!g_attr_set) {
-    GP_HIP(c, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + NB) * 8));
     GP_HIP(c, hipFuncSetAttribute((const void*)trinv_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + 4096) * 8));
     g_attr_set = true;
   }
   hipLaunchKernelGGL(zero_kernel, dim3(1024), dim3(256), 0, st, Linv, bs * batch);
   for (int j = 0; j < nt; ++j) {
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(1024), (NB * NB + NB) * 8, st, A, ld, bs, j, fail_flag);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(1024), 0, st, A, ld, bs, j, fail_flag);
     hipLaunchKernelGGL(trinv_diag_kernel, dim3(batch), dim3(1024), (NB * NB + 4096) * 8, st, A, ld, bs, j, Linv);
     const int rem = nt - j - 1;
     if (rem > 0) {
@@ -156,6 +215,7 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
   r.B = Linv; r.ldb = ld; r.sB = bs;   // B(k,j) = X[k][j] -> FREE_CONTIG
   r.C = Inv; r.ldc = ld; r.sC = bs;
   r.K = Mp; r.alpha = 1.0; r.beta = 0.0; r.tri = 0;
+  if (splitk_ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % 4 == 0) { r.splits = 4; r.ws = splitk_ws; }
   launch_gemm(st, FREE_CONTIG, FREE_CONTIG, Mp, Mp, batch, r);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -300,19 +360,23 @@ int run_global_step(gp_ctx* c) {
                      c->KmmKeep);
   GP_HIP(c, hipGetLastError());
   // factorise [Kmm ; A] in place, invert.  T1 is the 2 x 128 x Mp work panel.
-  int rc = potrf_inverse_batched(c, st, Mp, 2, c->Kmm, c->Linv, c->Inv, c->T1, c->gs + GS_LOGDET_K, failf);
+  // split-k workspace: the phase-1 partial buffer is free during the global step (>= 600 tiles)
+  double* ws = ((size_t)2 * (Mp / TILE) * (Mp / TILE) * 4 * TILE * TILE <= c->part_doubles) ? c->part : nullptr;
+  int rc = potrf_inverse_batched(c, st, Mp, 2, c->Kmm, c->Linv, c->Inv, c->T1, c->gs + GS_LOGDET_K, failf, ws);
   if (rc != GP_OK) return rc;
   double* Ki = c->Inv;
   double* P = c->Inv + mm;
   // E = P C ; PsiE = Psi2 E ; T1 = E E^T ; T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki
   GemmP g;
   g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
+  const bool sk = ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % 4 == 0;
+  if (sk) { g.splits = 4; g.ws = ws; }
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.A = Psi2; g.lda = Mp; g.B = c->E; g.ldb = Dp; g.C = c->PsiE; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
-  launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g);
+  { const int sps = g.splits; if ((Dp / KC) % 4 != 0 || Dp < 256) g.splits = 1; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
   g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;
@@ -366,7 +430,7 @@ extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double
   GP_HIP(c, hipMalloc((void**)&dT, (long)NB * Mp * 8)); GP_HIP(c, hipMalloc((void**)&dS, 64));
   GP_HIP(c, hipMemcpy(dA, h.data(), mm * 8, hipMemcpyHostToDevice));
   GP_HIP(c, hipMemset(dS, 0, 64));
-  int rc = potrf_inverse_batched(c, nullptr, Mp, 1, dA, dLi, dInv, dT, dS, dS + 1);
+  int rc = potrf_inverse_batched(c, nullptr, Mp, 1, dA, dLi, dInv, dT, dS, dS + 1, nullptr);
   if (rc == GP_OK) {
     double s[2];
     GP_HIP(c, hipDeviceSynchronize());

@@ -1,0 +1,42 @@
+"""predict.py's callback (predict.py:116-144) on the GPU against the oracle restatement of the same call sequence."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_predict_callback_matches_oracle():
+    from gparml_amd.predict import Predictor
+    from oracle import factorised as Fz
+    from oracle import literal as L
+    d = Fz.synthetic_shard(80, 4, 9, 3, regime='B', seed=31, zseed=32, alpha_value=0.6)
+    M, Q, D, N = 9, 3, 4, 80
+    train = L.PartialTermsOracle(d['Z'], d['sf2'], d['alpha'], d['beta'], M, Q, N, D)
+    train.set_data(d['Y'], d['X_mu'], d['X_S'], True)
+    st = train.get_local_statistics()
+    acc = dict(sum_YYT=st['sum_YYT'], sum_exp_K_mi_K_im=st['sum_exp_K_mi_K_im'], sum_exp_K_miY=st['exp_K_miY'],
+               sum_exp_K_ii=st['sum_exp_K_ii'], sum_KL=st['KL'])
+    rs = np.random.RandomState(5)
+    Yt = rs.randn(3, D)
+    Xm, Xs = rs.randn(3, Q), rs.uniform(0.2, 0.8, size=(3, Q))
+    gs = dict(Z=d['Z'], sf2=d['sf2'], alpha=d['alpha'], beta=d['beta'])
+    p = Predictor(gs, acc, N, D)
+    p.Y_test, p.shape = Yt, Xm.shape
+    p.bounds = [(None, None)] * Xm.size + [(0, None)] * Xm.size
+    x = np.concatenate((Xm.flatten(), np.log(np.exp(Xs.flatten()) - 1.0)))
+    f, g = p.likelihood_and_gradient(x)
+    # oracle: the same sequence with the literal restatement of partial_terms
+    o = L.PartialTermsOracle(d['Z'], d['sf2'], d['alpha'], d['beta'], M, Q, N, D)
+    o.set_data(Yt, Xm, Xs, True)
+    new = o.get_local_statistics()
+    o.set_local_statistics(acc['sum_YYT'] + new['sum_YYT'], acc['sum_exp_K_mi_K_im'] + new['sum_exp_K_mi_K_im'],
+                           acc['sum_exp_K_miY'] + new['exp_K_miY'], acc['sum_exp_K_ii'] + new['sum_exp_K_ii'], acc['sum_KL'] + new['KL'])
+    fo = -o.logmarglik()
+    go = -np.concatenate((o.grad_X_mu().flatten(), o.grad_X_S().flatten() * (1.0 / (1.0 + np.exp(-x[Xm.size:])))))
+    assert_close(f, fo, 1e-6, what='predict f')
+    assert_close(g, go, 1e-5, what='predict grad')
+    # and a short optimisation decreases the objective
+    res = p.test(Yt, Xm, Xs, iterations=3)
+    assert -res[2] <= f + 1e-9

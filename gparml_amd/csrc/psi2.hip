@@ -137,9 +137,9 @@ struct PB2Args {
   long N, Np; int M, Mp, Q, groups_per_block;
 };
 
-constexpr int MC = 4;   // inducing rows per pass: one LEA[m'][n] load and one uniform z_m' vector serve MC pair terms
-
-template <int QT>
+// MC inducing rows per pass: one LEA[m'][n] load and one uniform z_m' vector serve MC pair terms (MC = 4 for Q <= 16; the
+// register arrays p[MC][Q], t[MC][Q] force MC = 1 for larger Q)
+template <int QT, int MC>
 __global__ void __launch_bounds__(256, 2) psi2_rows_kernel(PB2Args a) {
   // LET holds LEA (m-major): exponent(n; m, m') = LEA[m][n] + LEA[m'][n] + sum_q p_mq z_m'q with p_mq = -2 V_nq z_mq.
   // Per point the running sums sr, zr_q, z2r_q, zt_q live in a.pp (global, touched once per MC rows), so the inner loop
@@ -336,9 +336,9 @@ int run_phase1_b(gp_ctx* c) {
   return GP_OK;
 }
 
-template <int QT>
+template <int QT, int MC>
 static void launch_rows(gp_ctx* c, const PB2Args& a, int blocks) {
-  hipLaunchKernelGGL((psi2_rows_kernel<QT>), dim3(blocks), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL((psi2_rows_kernel<QT, MC>), dim3(blocks), dim3(256), 0, c->stream, a);
 }
 
 int run_phase2_b(gp_ctx* c) {
@@ -350,11 +350,11 @@ int run_phase2_b(gp_ctx* c) {
   const long groups = (c->N + 255) / 256;
   a.groups_per_block = (int)((groups + c->pb_blocks - 1) / c->pb_blocks);
   const int blocks = (int)((groups + a.groups_per_block - 1) / a.groups_per_block);
-  if (c->Q <= 4) launch_rows<4>(c, a, blocks);
-  else if (c->Q <= 10) launch_rows<10>(c, a, blocks);
-  else if (c->Q <= 16) launch_rows<16>(c, a, blocks);
-  else if (c->Q <= 32) launch_rows<32>(c, a, blocks);
-  else launch_rows<64>(c, a, blocks);
+  if (c->Q <= 4) launch_rows<4, 4>(c, a, blocks);
+  else if (c->Q <= 10) launch_rows<10, 4>(c, a, blocks);
+  else if (c->Q <= 16) launch_rows<16, 2>(c, a, blocks);
+  else if (c->Q <= 32) launch_rows<32, 1>(c, a, blocks);
+  else launch_rows<64, 1>(c, a, blocks);
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_points_finish_kernel, dim3(c->pb_blocks), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());

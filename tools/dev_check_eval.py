@@ -12,7 +12,7 @@ ok = True
 cases = [(300, 5, 20, 3, 'A', False), (300, 5, 20, 3, 'A', True), (1000, 7, 130, 10, 'A', False), (1000, 7, 130, 10, 'A', True),
          (5000, 100, 512, 10, 'A', False), (777, 3, 5, 1, 'A', True), (2000, 10, 128, 13, 'A', False), (900, 4, 64, 20, 'A', True)]
 if len(sys.argv) > 1 and sys.argv[1] == 'B':
-    cases = [(300, 5, 20, 3, 'B', True), (1000, 7, 130, 10, 'B', True), (500, 4, 2, 2, 'B', True), (777, 3, 5, 1, 'B', True)]
+    cases = [(300, 5, 20, 3, 'B', True), (1000, 7, 130, 10, 'B', True), (500, 4, 2, 2, 'B', True), (400, 3, 20, 20, 'B', True), (300, 2, 12, 40, 'B', True)]
 for (N, D, M, Q, regime, emb) in cases:
     d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=1, zseed=2)
     eng = ShardEngine(N, D, M, Q)

@@ -75,13 +75,17 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
 }
 
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int tiles_x, int tiles_y) {
-  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x, bz = blockIdx.y;
+  // grid (tiles * 16, batch): 16 blocks of 256 threads per 128x128 tile, 4 elements each
+  const int tile = blockIdx.x >> 4, sub = blockIdx.x & 15;
+  const int bx = tile % tiles_x, by = tile / tiles_x, bz = blockIdx.y;
   if (p.tri == 1 && bx > by) return;
   if (p.tri == 2 && bx < by) return;
   const int bi = bz % p.inner, bo = bz / p.inner;
   double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
   const double* w = p.ws + (((long)bz * tiles_y + by) * tiles_x + bx) * p.splits * (TILE * TILE);
-  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = sub * 1024 + i * 256 + threadIdx.x;
     double s = 0.0;
     for (int sp = 0; sp < p.splits; ++sp) s += w[(long)sp * (TILE * TILE) + e];
     const long r = (long)by * TILE + (e >> 7), cc = (long)bx * TILE + (e & 127);
@@ -96,7 +100,7 @@ void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, 
   else if (la == FREE_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, K_CONTIG>), grid, block, 0, st, p);
   if (p.splits > 1)
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((n / TILE) * (m / TILE), batch), block, 0, st, p, n / TILE, m / TILE);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((n / TILE) * (m / TILE) * 16, batch), block, 0, st, p, n / TILE, m / TILE);
 }
 
 }  // namespace gp

@@ -191,4 +191,31 @@ __device__ __forceinline__ void mma_chunk_sb(const double* sA, const double* sB,
   }
 }
 
+// lowest-register variant: B operands in two groups of 8 (16 fewer VGPRs than mma_chunk_sb)
+template <Layout LA, Layout LB>
+__device__ __forceinline__ void mma_chunk_lo(const double* sA, const double* sB, Acc& acc, const LaneOfs& o) {
+#pragma unroll
+  for (int k4 = 0; k4 < KC / 4; ++k4) {
+    double a[4];
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar)
+      a[ar] = (LA == FREE_CONTIG) ? sA[o.a[0] + 4 * k4 * LDS_RC + 16 * ar] : sA[o.a[k4] + 256 * ar];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int bc = 8 * h + j;
+        b[j] = (LB == FREE_CONTIG)
+                   ? sB[o.b[0] + 4 * k4 * LDS_RC + 4 * bc]
+                   : sB[o.b[k4 & 1] + (bc & 1) * 64 + ((bc >> 1) & 1) * 16 + (bc >> 2) * 256 + (((k4 >> 1) ^ (bc & 1)) << 3)];
+      }
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mfma444_acc(acc.v[ar][8 * h + j], a[ar], b[j]);
+    }
+  }
+}
+
 }  // namespace gp

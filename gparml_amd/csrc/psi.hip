@@ -521,10 +521,6 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
 #pragma unroll
     for (int bc = 0; bc < NRB; ++bc) r[am][bc] = 0.0;
   const int crow = lane >> 2, ccg = lane & 3;                     // coalesced slab load: row, 16-column group
-  if (p.dbg & 12) {
-    const bool late = (p.dbg & 4) ? (((blockIdx.x >> 3) & 32) != 0) : (((blockIdx.x >> 3) & 1) != 0);
-    if (late) { const long t_end = wall_clock64() + 10000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(64); }
-  }
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
@@ -541,12 +537,11 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
         tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
         tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
       }
-      if (!(p.dbg & 2)) mma_chunk_sb<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+      mma_chunk_lo<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
       dma_wait();
       __syncthreads();
     }
     mfma_drain(acc.v[3][15]);
-    if (p.dbg & 1) { __syncthreads(); continue; }
     // ---- epilogue: all staging buffers are free now
     {
       const double2* src = reinterpret_cast<const double2*>(p.Xa + n0 * p.CXp);
@@ -563,7 +558,7 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
     for (int ar = 0; ar < 4; ++ar) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(slab + crow * SLAB_LD + 16 * ccg + 2 * i) = kv[i];
-      if (ar < 3 && !(p.dbg & 64)) {
+      if (ar < 3) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const double2*>(kbase + (long)(16 * (ar + 1)) * p.ld + 2 * i);
       }
@@ -580,12 +575,10 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
         for (int am = 0; am < 4; ++am) a[am] = slab[(4 * k4 + lk) * SLAB_LD + 16 * am + lr];
 #pragma unroll
         for (int bc = 0; bc < NRB; ++bc) b[bc] = xrow[(4 * k4 + lk) * p.CXp + 4 * bc];   // CXp == 4 * NRB
-        if (!(p.dbg & 32)) {
 #pragma unroll
         for (int am = 0; am < 4; ++am)
 #pragma unroll
           for (int bc = 0; bc < NRB; ++bc) mfma444_acc(r[am][bc], a[am], b[bc]);
-        }
       }
     }
     mfma_drain(r[3][NRB - 1]);   // hipcc may spill r[] around the k-loop: its MFMAs must have retired first
@@ -603,18 +596,25 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
 // R = sum of the (slice, wave-row) partials; then the data parts of grad_Z / grad_alpha
 //   fixedA (Xa = [mu, mu^2, 1]):  gZ = a (R1 - Z R0),  ga = -1/2 sum_m (R2 - 2 Z R1 + Z^2 R0)      [regime A, fixed embeddings]
 //   general (Xa = [u mu, u, 1]):  gZ = R1 - Z R2'  with R1 = W^T(u mu), R2' = W^T u; ga comes from the per-point kernel
-__global__ void __launch_bounds__(64) p2_reduce_kernel(const double* __restrict__ Rpart, int nparts, int Mp, int CXp, int M, int Q,
-                                                       const double* __restrict__ Z, const double* __restrict__ alpha, int fixedA,
-                                                       double* __restrict__ gZ, double* __restrict__ gapart) {
+__global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict__ Rpart, int nparts, int Mp, int CXp, int M, int Q,
+                                                        const double* __restrict__ Z, const double* __restrict__ alpha, int fixedA,
+                                                        double* __restrict__ gZ, double* __restrict__ gapart) {
+  // one block per inducing row m: 256 threads split the partial index, then tree-reduce per column
   const int m = blockIdx.x;
+  __shared__ double red[256];
   __shared__ double R[512];
-  for (int c = threadIdx.x; c < CXp; c += 64) {
+  for (int c0 = 0; c0 < CXp; c0 += 8) {
+    // 8 columns x 32 part-lanes per pass
+    const int c = c0 + (threadIdx.x & 7), pl = threadIdx.x >> 3;
     double s = 0.0;
-    for (int i = 0; i < nparts; ++i) s += Rpart[((long)i * Mp + m) * CXp + c];
-    R[c] = s;
+    if (c < CXp) for (int i = pl; i < nparts; i += 32) s += Rpart[((long)i * Mp + m) * CXp + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k >= 8; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x < 8 && c0 + threadIdx.x < CXp) R[c0 + threadIdx.x] = red[threadIdx.x];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int q = threadIdx.x; q < Q; q += 64) {
+  for (int q = threadIdx.x; q < Q; q += 256) {
     const double z = Z[(long)m * Q + q];
     if (fixedA) {
       const double r1 = R[q], r2 = R[Q + q], r0 = R[2 * Q];
@@ -702,7 +702,7 @@ int run_phase2(gp_ctx* c) {
   double* gZ = c->grads;
   double* ga = c->grads + (long)c->M * c->Q;
   // T2 is free after the global step: per-row alpha partials [M][Q]
-  hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(64), 0, c->stream, c->Rpart, 2 * S, c->Mp, c->CXp, c->M, c->Q, c->Z, c->alpha,
+  hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(256), 0, c->stream, c->Rpart, 2 * S, c->Mp, c->CXp, c->M, c->Q, c->Z, c->alpha,
                      ppath ? 0 : 1, gZ, c->T2);
   GP_HIP(c, hipGetLastError());
   if (ppath) {

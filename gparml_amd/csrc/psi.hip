@@ -98,27 +98,36 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 // arrives through wide scalar loads and feeds the FMAs as SGPR operands; no guards in the q loop (padding has u = 0).
 template <int QP>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
-                                                   long N, long Np, int M, int Q, long ld) {
-  const int col = blockIdx.x * 128 + (threadIdx.x & 127);
-  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-  const long row0 = blockIdx.y * 64L + half * 32;
-  const bool colok = col < M;
-  double z[QP];
+                                                   long N, long Np, int M, int Q, long ld, int dbg) {
+  // one wave = 128 columns (two adjacent per lane -> one 16-byte store per lane, 1 KB per wave-row) x 16 rows; the row's
+  // packed [mu | u | lnc1] record is wave-uniform and comes through scalar loads
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = blockIdx.x * 128 + 2 * lane;
+  const long row0 = blockIdx.y * 64L + wave * 16;
+  const bool ok0 = col < M, ok1 = col + 1 < M;
+  double z0[QP], z1[QP];
 #pragma unroll
-  for (int q = 0; q < QP; ++q) z[q] = (q < Q && colok) ? Z[(long)col * Q + q] : 0.0;
+  for (int q = 0; q < QP; ++q) {
+    z0[q] = (q < Q && ok0) ? Z[(long)col * Q + q] : 0.0;
+    z1[q] = (q < Q && ok1) ? Z[(long)(col + 1) * Q + q] : 0.0;
+  }
   constexpr int W = 2 * QP + 2;   // row width of PU (doubles), a multiple of 2
 #pragma unroll 2
-  for (int r = 0; r < 32; ++r) {
+  for (int r = 0; r < 16; ++r) {
     const long n = row0 + r;       // Np is a multiple of 64: always in range
     const double* row = PU + n * W;
-    double e = 0.0;
+    double e0 = 0.0, e1 = 0.0;
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
-      const double d = row[q] - z[q];
-      e = fma(row[QP + q] * d, d, e);
+      const double d0 = row[q] - z0[q], d1 = row[q] - z1[q];
+      e0 = fma(row[QP + q] * d0, d0, e0);
+      e1 = fma(row[QP + q] * d1, d1, e1);
     }
-    const double v = (n < N && colok) ? exp(row[2 * QP] - 0.5 * e) : 0.0;
-    Kaug[n * ld + col] = v;
+    double2 v;
+    v.x = (n < N && ok0) ? exp(row[2 * QP] - 0.5 * e0) : 0.0;
+    v.y = (n < N && ok1) ? exp(row[2 * QP] - 0.5 * e1) : 0.0;
+    *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
   }
 }
 
@@ -258,7 +267,8 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 template <int QP>
 static void launch_psi1(gp_ctx* c) {
   dim3 grid(c->Mp / 128, (unsigned)(c->Np / 64));
-  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Q, (long)c->LDK);
+  static int dbg = -1; if (dbg < 0) { const char* e = getenv("GP_PSI1_DBG"); dbg = e ? atoi(e) : 0; }
+  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Q, (long)c->LDK, dbg);
 }
 
 int run_prep_and_generate(gp_ctx* c) {

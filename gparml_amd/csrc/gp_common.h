@@ -113,9 +113,15 @@ struct gp_ctx {
   // regime B (variances > 0): pairwise psi2 kernels; allocated on first use
   bool b_alloc = false;
   double* LE = nullptr;       // [Np][Mp]  1/2 ln c2_n - 1/2 sum_q w_nq (mu_nq - z_mq)^2   (n-major)
-  double* LET = nullptr;      // [Mp][Np]  same, m-major
+  double* LET = nullptr;      // LEA = LE + sum_q V_nq z_mq^2, tiled [Np/64][Mp][64]
   double* Vn = nullptr;       // [Np][Q]   -1/4 (alpha_q - w_nq)
   double* Wn = nullptr;       // [Np][Q]   w_nq = alpha_q / (2 alpha_q S_nq + 1)
+  double* V2P = nullptr;      // [Np][QB]  -2 V_nq, zero-padded to the kernels' compile-time width QB
+  double* V2T = nullptr;      // [QB][Np]  -2 V_nq, q-major
+  double* WT = nullptr;       // [Q][Np]   w_nq, q-major
+  double* MUT = nullptr;      // [Q][Np]   mu_nq, q-major
+  double* ZP = nullptr;       // [Mp][QB]  Z zero-padded (rows >= M and columns >= Q are zero)
+  int QB = 0;                 // 4, 10, 16, 32 or 64: smallest instantiated width >= Q
   double* lnc2h = nullptr;    // [Np]      1/2 ln c2_n
   double* DZ2 = nullptr;      // [M][M][Q] (z_mq - z_m'q)^2
   double* Gpart = nullptr;    // [pb_blocks][M][Q] per-block grad_Z partials of the psi2 part

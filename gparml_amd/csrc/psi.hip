@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 // arrives through wide scalar loads and feeds the FMAs as SGPR operands; no guards in the q loop (padding has u = 0).
 template <int QP>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
-                                                   long N, long Np, int M, int Q, long ld, int dbg) {
+                                                   long N, long Np, int M, int Q, long ld) {
   // one wave = 128 columns (two adjacent per lane -> one 16-byte store per lane, 1 KB per wave-row) x 16 rows; the row's
   // packed [mu | u | lnc1] record is wave-uniform and comes through scalar loads
   const int lane = threadIdx.x & 63;
@@ -267,8 +267,7 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 template <int QP>
 static void launch_psi1(gp_ctx* c) {
   dim3 grid(c->Mp / 128, (unsigned)(c->Np / 64));
-  static int dbg = -1; if (dbg < 0) { const char* e = getenv("GP_PSI1_DBG"); dbg = e ? atoi(e) : 0; }
-  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Q, (long)c->LDK, dbg);
+  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Q, (long)c->LDK);
 }
 
 int run_prep_and_generate(gp_ctx* c) {

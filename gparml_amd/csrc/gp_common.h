@@ -113,13 +113,13 @@ struct gp_ctx {
   // regime B (variances > 0): pairwise psi2 kernels; allocated on first use
   bool b_alloc = false;
   double* LE = nullptr;       // [Np][Mp]  1/2 ln c2_n - 1/2 sum_q w_nq (mu_nq - z_mq)^2   (n-major)
-  double* LET = nullptr;      // LEA = LE + sum_q V_nq z_mq^2, tiled [Np/64][Mp][64]
+  double* LET = nullptr;      // [Np][Mp]  LEA = LE + sum_q V_nq z_mq^2 (n-major)
   double* Vn = nullptr;       // [Np][Q]   -1/4 (alpha_q - w_nq)
   double* Wn = nullptr;       // [Np][Q]   w_nq = alpha_q / (2 alpha_q S_nq + 1)
   double* V2P = nullptr;      // [Np][QB]  -2 V_nq, zero-padded to the kernels' compile-time width QB
-  double* V2T = nullptr;      // [QB][Np]  -2 V_nq, q-major
-  double* WT = nullptr;       // [Q][Np]   w_nq, q-major
-  double* MUT = nullptr;      // [Q][Np]   mu_nq, q-major
+  double* WP = nullptr;       // [Np][QB]  w_nq, zero-padded
+  double* MUP = nullptr;      // [Np][QB]  mu_nq, zero-padded
+  double* alphaP = nullptr;   // [QB]      alpha, zero-padded
   double* ZP = nullptr;       // [Mp][QB]  Z zero-padded (rows >= M and columns >= Q are zero)
   int QB = 0;                 // 4, 10, 16, 32 or 64: smallest instantiated width >= Q
   double* lnc2h = nullptr;    // [Np]      1/2 ln c2_n
@@ -128,6 +128,7 @@ struct gp_ctx {
   double* gapart2 = nullptr;  // [pb_blocks][Q]
   double* pp = nullptr;       // [Np][3Q+1] per-point running sums sr, zr, z2r, zt of the psi2 rows kernel
   int pb_blocks = 0;
+  int nslab = 0, ppb = 0;     // regime-B phase-2 pair kernel: 64-column slabs of M, points per workgroup
   int* ptiles = nullptr;      // upper-triangular 16x16 tile table for the psi2 pair kernel
   int n_ptiles = 0;
   // CG vectors (resident): grad_latest/new/old (2,N,Q) each

@@ -12,13 +12,15 @@
 
 namespace gp {
 
+constexpr double kPadLog = -1.0e5;   // log-density of padded rows / columns / points: exp(kPadLog + anything) == 0
+
 // ---------------------------------------------------------------------------------------------- tables
 // per-point tables and LE in both layouts; thread = point for LET (coalesced along n), thread = column for LE
 __global__ void __launch_bounds__(256) b_tables_kernel(const double* __restrict__ mu, const double* __restrict__ S,
                                                         const double* __restrict__ alpha, long N, long Np, int Q, double sf2,
                                                         double* __restrict__ Vn, double* __restrict__ Wn, double* __restrict__ lnc2h,
-                                                        double* __restrict__ V2P, int QB, double* __restrict__ V2T,
-                                                        double* __restrict__ WT, double* __restrict__ MUT) {
+                                                        double* __restrict__ V2P, int QB, double* __restrict__ WP,
+                                                        double* __restrict__ MUP) {
   for (long n = blockIdx.x * 256L + threadIdx.x; n < Np; n += (long)gridDim.x * 256L) {
     double l = log(sf2);   // half of ln c2 = ln sf2 - 1/4 sum ln(2 a S + 1)
     for (int q = 0; q < Q; ++q) {
@@ -27,9 +29,8 @@ __global__ void __launch_bounds__(256) b_tables_kernel(const double* __restrict_
       Wn[n * Q + q] = w;
       Vn[n * Q + q] = -0.25 * (a - w);
       V2P[n * QB + q] = 0.5 * (a - w);      // -2 V_nq (columns >= Q stay zero from the allocation)
-      V2T[q * Np + n] = 0.5 * (a - w);      // the same, q-major (coalesced per-lane reads in the rows kernel)
-      WT[q * Np + n] = w;
-      MUT[q * Np + n] = mu[n * Q + q];
+      WP[n * QB + q] = w;
+      MUP[n * QB + q] = mu[n * Q + q];
       l -= 0.25 * log(d2);
     }
     lnc2h[n] = l;
@@ -38,33 +39,25 @@ __global__ void __launch_bounds__(256) b_tables_kernel(const double* __restrict_
 
 __global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ mu, const double* __restrict__ Wn, const double* __restrict__ Vn,
                                                     const double* __restrict__ lnc2h, const double* __restrict__ Z, long N, long Np,
-                                                    int M, int Mp, int Q, double* __restrict__ LE, double* __restrict__ LET) {
-  // block: 16 rows (n) x 16 cols (m) tile computed once, written in both layouts through LDS
-  __shared__ double tile[16][17];
+                                                    int M, int Mp, int Q, double* __restrict__ LE, double* __restrict__ LEA) {
+  // both tables are n-major [Np][Mp]; padded entries hold kPadLog (their exp is exactly 0)
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const long n = blockIdx.y * 16L + ty;
   const int m = blockIdx.x * 16 + tx;
-  double e = 0.0;
+  double e = kPadLog, ea = kPadLog;
   if (n < N && m < M) {
+    e = 0.0;
     for (int q = 0; q < Q; ++q) {
       const double d = mu[n * Q + q] - Z[(long)m * Q + q];
       e = fma(Wn[n * Q + q] * d, d, e);
     }
     e = lnc2h[n] - 0.5 * e;
-  } else {
-    e = -1e300;   // exp() of a padded entry is exactly 0
-  }
-  LE[n * Mp + m] = e;
-  // LEA = LE + sum_q V_nq z_mq^2: with it the pair exponent is LEA_nm + LEA_nm' - 2 sum_q V_nq z_mq z_m'q
-  double ea = e;
-  if (n < N && m < M) {
+    // LEA = LE + sum_q V_nq z_mq^2: with it the pair exponent is LEA_nm + LEA_nm' - 2 sum_q V_nq z_mq z_m'q
+    ea = e;
     for (int q = 0; q < Q; ++q) { const double z = Z[(long)m * Q + q]; ea = fma(Vn[n * Q + q] * z, z, ea); }
   }
-  tile[ty][tx] = ea;
-  __syncthreads();
-  const long n2 = blockIdx.y * 16L + tx;
-  const int m2 = blockIdx.x * 16 + ty;
-  LET[((n2 >> 6) * (long)Mp + m2) * 64 + (n2 & 63)] = tile[tx][ty];   // tiled [Np/64][Mp][64]: a wave's stream is contiguous
+  LE[n * Mp + m] = e;
+  LEA[n * Mp + m] = ea;
 }
 
 __global__ void __launch_bounds__(256) dz2_kernel(const double* __restrict__ Z, int M, int Q, double* __restrict__ DZ2) {
@@ -86,26 +79,25 @@ __global__ void __launch_bounds__(256) zpad_kernel(const double* __restrict__ Z,
   }
 }
 
-// exp for the pair kernels: 20 FP64 instructions, no table, no special cases beyond underflow (the argument is a finite
-// log-density or the -1e300 padding marker).  x = k ln2 + r, |r| <= ln2/2; degree-13 Taylor (truncation r^14/14! < 5e-18
-// relative); the result is exact to ~2 ulp, far inside the 1e-6 / 1e-5 parity budget.
+// exp for the pair kernels: 17 FP64 instructions, no table, no special cases.  x = k ln2 + r, |r| <= ln2/2; degree-11
+// near-minimax polynomial (Chebyshev-node fit in extended precision: approximation error 1.6e-17, error of the double
+// evaluation 1.7e-16 relative -- far inside the 1e-6 / 1e-5 parity budget).  Arguments are finite log-densities or sums
+// of the padding marker kPadLog; anything below about -745 returns exactly 0 through ldexp's underflow.  (Not valid for
+// |x| > 1e290 -- that is why the padding marker is -1e5 and not -1e300.)
 __device__ __forceinline__ double fexp(double x) {
-  x = fmax(x, -745.5);
   const double k = rint(x * 1.4426950408889634074);
   double r = fma(k, -6.93147180369123816490e-01, x);
   r = fma(k, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821614599e-10;              // 1/13!
-  p = fma(p, r, 2.0876756987868098979e-09);          // 1/12!
-  p = fma(p, r, 2.5052108385441718775e-08);          // 1/11!
-  p = fma(p, r, 2.7557319223985890653e-07);          // 1/10!
-  p = fma(p, r, 2.7557319223985892511e-06);          // 1/9!
-  p = fma(p, r, 2.4801587301587301566e-05);          // 1/8!
-  p = fma(p, r, 1.9841269841269841253e-04);          // 1/7!
-  p = fma(p, r, 1.3888888888888889419e-03);          // 1/6!
-  p = fma(p, r, 8.3333333333333332177e-03);          // 1/5!
-  p = fma(p, r, 4.1666666666666664354e-02);          // 1/4!
-  p = fma(p, r, 1.6666666666666665741e-01);          // 1/3!
-  p = fma(p, r, 0.5);
+  double p = 0x1.af633307a1519p-26;
+  p = fma(p, r, 0x1.28b409b390145p-22);
+  p = fma(p, r, 0x1.71ddf56b7e3cbp-19);
+  p = fma(p, r, 0x1.a01991a5ecd16p-16);
+  p = fma(p, r, 0x1.a01a01b143788p-13);
+  p = fma(p, r, 0x1.6c16c187ffce5p-10);
+  p = fma(p, r, 0x1.111111110f247p-7);
+  p = fma(p, r, 0x1.555555554f0aep-5);
+  p = fma(p, r, 0x1.555555555555ap-3);
+  p = fma(p, r, 0x1.0000000000011p-1);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   return ldexp(p, (int)k);
@@ -119,7 +111,7 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
                                                           int Mp, int S, double* __restrict__ part, int T) {
   // exponent = LE[n,m] + LE[n,m'] + sum_q V_nq dz2_q = LE + LE' + sum_q (-2 V_nq) * (-1/2 dz2_q): the per-pair vector lives in
   // registers, the per-point vector (-2V, zero-padded to QT) is wave-uniform -> scalar loads; four points per trip so
-  // the loads of a trip are in flight together.  Padded rows of LE hold -1e300 (exp -> 0), padded pairs are dropped by
+  // the loads of a trip are in flight together.  Padded rows of LE hold kPadLog (exp -> 0), padded pairs are dropped by
   // the reduce kernel.
   const int tile = blockIdx.x, slice = blockIdx.y;
   const int I = ptiles[2 * tile], J = ptiles[2 * tile + 1];
@@ -182,267 +174,116 @@ __global__ void fill_kernel(double* x, long n, double v) {
 }
 
 // ---------------------------------------------------------------------------------------------- phase 2
-// lane = point.  For every m: r = sum_m' T[m,m'], t_q = sum_m' T[m,m'] z_m'q with T = Bbar[m,m'] psi2_n[m,m'].
+// T_n = Bbar o psi2_n (symmetric M x M per point), r_n = T_n 1, t_n = T_n Z give the psi2 parts of every gradient:
 //   grad_Z psi2 part  G[m,k] += -a_k z_mk r + a_k t_k + w_k (2 mu_k r - z_mk r - t_k)          (partial_terms.py:190-205, x2 at :238)
 //   per point: sr, zr_q, z2r_q, zt_q -> quad = 4 mu^2 sr - 8 mu zr + 2 z2r + 2 zt
 //   grad_alpha += -1/4 quad/d2^2 - (S/d2) sr ; grad_X_mu += -w (2 mu sr - 2 zr) ; grad_X_S += 1/2 w^2 quad - w sr
+//                                                                               (partial_terms.py:273-284, 388-394, 421-427)
+// Layout: a wave owns 64 inducing COLUMNS m' (one per lane) and walks over points n and rows m, both wave-uniform:
+//   exponent(n; m, m') = LEA[n,m] + LEA[n,m'] + sum_q z_mq * (-2 V_nq z_m'q)
+// so the row operands (z_m, LEA[n,m]) are scalar loads, the column operands (z_m', zz = -2 V_n z_m', LEA[n,m']) live in
+// the lane's registers, Bbar[m][m'] is one coalesced load per step, and by the symmetry of T the lane accumulates its own
+// column sums r[m'] = sum_m T, t[m'][q] = sum_m T z_mq with no cross-lane traffic.  After the M rows of a point: grad_Z of
+// the lane's column accumulates in registers over all points; the per-point sums are wave-reduced, combined over the
+// workgroup's four column slabs in LDS and written once per (point, slab group).  Nothing is re-streamed per row block
+// and the register need is 8 QT (KEEP) or 4 QT (!KEEP: z_m' re-read per point, grad_Z accumulated in memory) VGPRs.
 struct PB2Args {
-  const double* LET; const double* Vn; const double* Wn; const double* mu; const double* S; const double* DZ2; const double* Z;
-  const double* Bbar; const double* alpha; double* Gpart; double* gapart2; double* gmu; double* gS; double* pp;
-  const double* V2P; const double* ZP; const double* V2T; const double* WT; const double* MUT;
-  long N, Np; int M, Mp, Q, QB, groups_per_block;   // QB: padded Q (row stride of the q-major per-point tables and of pp)
+  const double* Wn; const double* mu; const double* S; const double* alpha;
+  double* Gpart; double* gapart2; double* gmu; double* gS; double* pp;
+  long N, Np; int M, Mp, Q, QB, nslab, ppb;   // nslab = ceil(M/64) column slabs; ppb points per workgroup
 };
 
-// MC inducing rows per pass: one LEA[m'][n] load and one uniform z_m' vector serve MC pair terms (MC = 4 for Q <= 16; the
-// register arrays p[MC][Q], t[MC][Q] force MC = 1 for larger Q)
-template <int QT, int MC>
-__global__ void __launch_bounds__(256, 2) psi2_rows_wide_kernel(PB2Args a) {
-  // LET holds LEA (m-major): exponent(n; m, m') = LEA[m][n] + LEA[m'][n] + sum_q p_mq z_m'q with p_mq = -2 V_nq z_mq.
-  // Per point the running sums sr, zr_q, z2r_q, zt_q live in a.pp (global, touched once per MC rows), so the inner loop
-  // keeps only p[MC][Q], t[MC][Q] and r[MC] in registers.
-  __shared__ double red[4][MC][QT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;
-  const int PW = 3 * a.QB + 1;
-  for (int grp = 0; grp < a.groups_per_block; ++grp) {
-    const long n = ((long)blockIdx.x * a.groups_per_block + grp) * 256 + tid;
-    const bool live = n < a.N;
-    const long nn = live ? n : 0;
-    double* ppn = a.pp + nn;                       // running sums, one row of Np doubles per quantity
-    if (live) for (int k = 0; k < PW; ++k) ppn[(long)k * a.Np] = 0.0;
-    const double* lcol = a.LET + (nn >> 6) * (long)a.Mp * 64 + (nn & 63);   // element m at lcol[m * 64]
-    for (int m0 = 0; m0 < a.M; m0 += MC) {
-      double p[MC][QT], t[MC][QT], r[MC], lem[MC];
-#pragma unroll
-      for (int k = 0; k < MC; ++k) {
-        const double* zm = a.Z + (long)(m0 + k) * a.Q;               // wave-uniform (rows >= M are zero)
-        lem[k] = (live && m0 + k < a.M) ? lcol[(long)(m0 + k) * 64] : -1e300;
-        r[k] = 0.0;
-#pragma unroll
-        for (int q = 0; q < QT; ++q) { p[k][q] = (q < a.Q) ? -2.0 * a.Vn[nn * a.Q + q] * zm[q] : 0.0; t[k][q] = 0.0; }
-      }
-      const double* brow = a.Bbar + (long)m0 * a.Mp;                 // wave-uniform, MC consecutive rows
-#pragma unroll 2
-      for (int m2 = 0; m2 < a.M; ++m2) {
-        const double* z2 = a.Z + (long)m2 * a.Q;                     // wave-uniform
-        const double l2 = lcol[(long)m2 * 64];
-        double zz[QT];
-#pragma unroll
-        for (int q = 0; q < QT; ++q) zz[q] = (q < a.Q) ? z2[q] : 0.0;
-#pragma unroll
-        for (int k = 0; k < MC; ++k) {
-          double e = lem[k] + l2;
-#pragma unroll
-          for (int q = 0; q < QT; ++q) e = fma(p[k][q], zz[q], e);
-          const double T = brow[(long)k * a.Mp + m2] * exp(e);
-          r[k] += T;
-#pragma unroll
-          for (int q = 0; q < QT; ++q) t[k][q] = fma(T, zz[q], t[k][q]);
-        }
-      }
-      // fold the MC rows into the per-point sums and the block-level grad_Z contribution
-      double dsr = 0.0;
-#pragma unroll
-      for (int k = 0; k < MC; ++k) {
-        const double* zm = a.Z + (long)(m0 + k) * a.Q;
-        const double rk = live ? r[k] : 0.0;
-        dsr += rk;
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-          if (q < a.Q) {
-            const double z = zm[q];
-            const double tq = live ? t[k][q] : 0.0;
-            if (live) {
-              double* p1 = ppn + (long)(1 + q) * a.Np;
-              double* p2 = ppn + (long)(1 + a.QB + q) * a.Np;
-              double* p3 = ppn + (long)(1 + 2 * a.QB + q) * a.Np;
-              *p1 = fma(z, rk, *p1);
-              *p2 = fma(z * z, rk, *p2);
-              *p3 = fma(z, tq, *p3);
-            }
-            const double w = a.Wn[nn * a.Q + q], mu = a.mu[nn * a.Q + q];
-            double g = -a.alpha[q] * (z * rk - tq) + w * (2.0 * mu * rk - z * rk - tq);
-            for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-            if (lane == 0) red[wave][k][q] = g;
-          }
-        }
-      }
-      if (live) ppn[0] += dsr;
-      __syncthreads();
-      if (tid < MC * a.Q) {
-        const int k = tid / a.Q, q = tid - k * a.Q;
-        if (m0 + k < a.M) {
-          const double s = red[0][k][q] + red[1][k][q] + red[2][k][q] + red[3][k][q];
-          double* dst = G + (long)(m0 + k) * a.Q + q;
-          *dst = ((grp == 0) ? 0.0 : *dst) + s;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// Q <= 16: the same scheme on the zero-padded tables (no q guards in the pair loop), the B-bar row block read through the
-// matrix' symmetry as MC consecutive doubles (one scalar load), the hand-rolled exp.  The LEA[m'][n] stream (one 512-byte
-// row piece per wave and m', re-read for every row block, far larger than L2 across the resident waves) is brought in
-// by LDS-DMA, RCH rows ahead of its use, each wave feeding its own double buffer: without it every m' step waits a full
-// HBM round trip (measured: 115 ms of 137 ms at N = 2e5, M = 512).
-constexpr int RCH = 8;
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-// two rows (j, j+1) of the wave's LDS chunk for this lane.  Inline asm on purpose: a compiler-visible LDS read makes
-// hipcc wait for every outstanding LDS-DMA (s_waitcnt vmcnt(0)) first, which would expose the prefetch it is there to hide.
-template <int J>
-__device__ __forceinline__ dbl2 lds_rows2(unsigned byte_addr) {
-  dbl2 v;
-  asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr), "n"(J), "n"(J + 1));
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-template <int QT, int MC>
-__global__ void __launch_bounds__(256, MC >= 4 ? 2 : 4) psi2_rows_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
-                                                           const double* __restrict__ LET, const double* __restrict__ V2P) {
-  // (the read-only tables are separate __restrict__ kernel arguments so that the wave-uniform reads become scalar loads)
-  __shared__ double red[4][MC][QT];
-  __shared__ __attribute__((aligned(16))) double lbuf[4][MC >= 4 ? 3 : 2][RCH][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;
-  constexpr int PW = 3 * QT + 1;                   // rows of pp: [sr | zr_q | z2r_q | zt_q], q padded to QT = QB
-  const int Mr = (a.M + RCH - 1) / RCH * RCH;       // <= Mp; rows >= M of LET hold -1e300, of ZP / Bbar zero
-  for (int grp = 0; grp < a.groups_per_block; ++grp) {
-    const long nw0 = ((long)blockIdx.x * a.groups_per_block + grp) * 256 + wave * 64;
-    const long n = nw0 + lane;
-    const bool live = n < a.N;
-    const long nn = live ? n : 0;
-    double* ppn = a.pp + nn;                       // running sums [sr | zr_q | z2r_q | zt_q], one row of Np doubles each
-    if (live) for (int k = 0; k < PW; ++k) ppn[(long)k * a.Np] = 0.0;
-    const double* lcol = LET + (nn >> 6) * (long)a.Mp * 64 + (nn & 63);     // element m at lcol[m * 64]
-    const double* v2 = a.V2T + nn;
-    // DMA source of this lane: LET is tiled [Np/64][Mp][64], so rows mb .. mb+RCH-1 of the wave's 64 points are RCH*512
-    // contiguous bytes; each instruction moves two rows (16 bytes per lane)
-    const double* dsrc = LET + min(nw0 >> 6, a.Np / 64 - 1) * (long)a.Mp * 64 + 2 * lane;
-    auto dma = [&](int buf, int mb) {
+
+template <int QT, bool KEEP>
+__global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_cols_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
+                                                        const double* __restrict__ LEA, const double* __restrict__ V2P,
+                                                        const double* __restrict__ WP, const double* __restrict__ MUP,
+                                                        const double* __restrict__ alphaP) {
+  constexpr int PW = 3 * QT + 1;
+  __shared__ double red[4][PW];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int slab = blockIdx.y * 4 + wave;
+  const bool active = slab < a.nslab;                    // idle waves (M not a multiple of 256) only join the barriers
+  const int mc = (active ? slab : 0) * 64 + lane;        // this lane's column m' (< Mp; columns >= M: LEA = kPadLog, ZP = 0)
+  double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;    // this workgroup's grad_Z partial (rows of its slabs)
+  double z[KEEP ? QT : 1], g[KEEP ? QT : 1];
+  if (KEEP) {
 #pragma unroll
-      for (int j = 0; j < RCH / 2; ++j)
-        __builtin_amdgcn_global_load_lds((gp::gbl_void*)(dsrc + (long)(mb + 2 * j) * 64), (gp::lds_void*)&lbuf[wave][buf][2 * j][0], 16, 0, 2);
-      // aux = 2 (nt): the stream must not evict the scalar operands (Z, Bbar) from L2 -- measured 158 -> 134 ms
-    };
-    const unsigned lbuf_addr = (unsigned)(unsigned long)(gp::lds_void*)&lbuf[wave][0][0][lane];
-    for (int m0 = 0; m0 < a.M; m0 += MC) {          // rows m0 .. m0+MC-1 (rows >= M: ZP rows are zero, LET rows are -1e300)
-      double p[MC][QT], t[MC][QT], r[MC], lem[MC];
-      dma(0, 0);
-      if (MC >= 4) dma(1, RCH);
+    for (int q = 0; q < QT; ++q) { z[q] = ZP[(long)mc * QT + q]; g[q] = 0.0; }
+  }
+  const long n0 = (long)blockIdx.x * a.ppb, n1 = min(a.N, n0 + a.ppb);
+  const int Mr = (a.M + 3) & ~3;                          // rows >= M: ZP rows are zero, LEA entries kPadLog
+  for (long n = n0; n < n1; ++n) {
+    double zz[QT], t[QT], r = 0.0;
+    if (active) {
+      const double* v2 = V2P + n * QT;                   // wave-uniform
 #pragma unroll
-      for (int k = 0; k < MC; ++k) {
-        const double* zm = ZP + (long)(m0 + k) * QT;                   // wave-uniform
-        lem[k] = live ? lcol[(long)(m0 + k) * 64] : -1e300;
-        r[k] = 0.0;
+      for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * (KEEP ? z[q] : ZP[(long)mc * QT + q]); t[q] = 0.0; }
+      const double* lrow = LEA + n * a.Mp;               // wave-uniform row of this point
+      const double lea = lrow[mc];
+      const double* bcol = Bbar + mc;
+      constexpr int U = QT <= 10 ? 4 : (QT <= 16 ? 2 : 1);   // rows per trip: U z-rows (2 QT SGPRs each) must fit the scalar file
+      for (int m = 0; m < Mr; m += U) {
+        double bb[U];
 #pragma unroll
-        for (int q = 0; q < QT; ++q) { p[k][q] = v2[(long)q * a.Np] * zm[q]; t[k][q] = 0.0; }
-      }
-      const double* bcol = Bbar + m0;                                  // Bbar[m'][m0 + k] = Bbar[m0 + k][m'] (symmetric)
-      // the uniform operands of step m' (z_m', Bbar[m'][m0..]) are scalar loads issued one step ahead of their use
-      double zc[QT], bc[MC];
+        for (int u = 0; u < U; ++u) bb[u] = bcol[(long)(m + u) * a.Mp];
 #pragma unroll
-      for (int q = 0; q < QT; ++q) zc[q] = ZP[q];
+        for (int u = 0; u < U; ++u) {
+          const double* zm = ZP + (long)(m + u) * QT;    // wave-uniform
+          double e = lrow[m + u] + lea;
 #pragma unroll
-      for (int k = 0; k < MC; ++k) bc[k] = bcol[k];
-      for (int mb = 0; mb < Mr; mb += RCH) {
-        constexpr int NB = MC >= 4 ? 3 : 2;         // LDS chunk buffers per wave (NB - 1 chunks in flight)
-        const int buf = (mb / RCH) % NB;
-        if (NB == 3 && mb + RCH < Mr) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else gp::dma_wait();
-        if (mb + (NB - 1) * RCH < Mr) dma((buf + NB - 1) % NB, mb + (NB - 1) * RCH);
-        const unsigned lds_addr = lbuf_addr + buf * (RCH * 64 * 8);
-        dbl2 lv;
+          for (int q = 0; q < QT; ++q) e = fma(zm[q], zz[q], e);
+          const double T = bb[u] * fexp(e);
+          r += T;
 #pragma unroll
-        for (int j = 0; j < RCH; ++j) {
-          if (j == 0) lv = lds_rows2<0>(lds_addr);
-          if (j == 2) lv = lds_rows2<2>(lds_addr);
-          if (j == 4) lv = lds_rows2<4>(lds_addr);
-          if (j == 6) lv = lds_rows2<6>(lds_addr);
-          const double l2 = (j & 1) ? lv.y : lv.x;
-          // SMEM returns out of order, so only lgkmcnt(0) is usable: touch the current operands first (that wait
-          // retires the loads issued one step ago), THEN issue the loads of the next step, then do the bulk of the work
-          double e[MC];
-#pragma unroll
-          for (int k = 0; k < MC; ++k) e[k] = fma(p[k][0], zc[0], lem[k] + l2);
-          __builtin_amdgcn_sched_barrier(0);
-          const int m2n = min(mb + j + 1, a.Mp - 1);
-          const double* z2 = ZP + (long)m2n * QT;                      // wave-uniform
-          const double* bb = bcol + (long)m2n * a.Mp;                  // wave-uniform, MC consecutive doubles
-          double zn[QT], bn[MC];
-#pragma unroll
-          for (int q = 0; q < QT; ++q) zn[q] = z2[q];
-#pragma unroll
-          for (int k = 0; k < MC; ++k) bn[k] = bb[k];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k = 0; k < MC; ++k) {
-#pragma unroll
-            for (int q = 1; q < QT; ++q) e[k] = fma(p[k][q], zc[q], e[k]);
-            const double T = bc[k] * fexp(e[k]);
-            r[k] += T;
-#pragma unroll
-            for (int q = 0; q < QT; ++q) t[k][q] = fma(T, zc[q], t[k][q]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < QT; ++q) zc[q] = zn[q];
-#pragma unroll
-          for (int k = 0; k < MC; ++k) bc[k] = bn[k];
+          for (int q = 0; q < QT; ++q) t[q] = fma(T, zm[q], t[q]);
         }
       }
-      // fold the MC rows into the per-point sums and the block-level grad_Z contribution.  All loads of the epilogue are
-      // issued together (one memory round trip per row block, not one per quantity).
-      double sv[PW], wv[QT], muv[QT];
+    } else {
 #pragma unroll
-      for (int i = 0; i < PW; ++i) sv[i] = ppn[(long)i * a.Np];
-#pragma unroll
-      for (int q = 0; q < QT; ++q) { wv[q] = a.WT[(long)q * a.Np + nn]; muv[q] = a.MUT[(long)q * a.Np + nn]; }
-#pragma unroll
-      for (int k = 0; k < MC; ++k) {
-        const double* zm = ZP + (long)(m0 + k) * QT;
-        const double rk = r[k];                                        // dead lanes: exp(-1e300) = 0 -> r = t = 0
-        sv[0] += rk;
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-          const double z = zm[q];
-          const double tq = t[k][q];
-          sv[1 + q] = fma(z, rk, sv[1 + q]);
-          sv[1 + QT + q] = fma(z * z, rk, sv[1 + QT + q]);
-          sv[1 + 2 * QT + q] = fma(z, tq, sv[1 + 2 * QT + q]);
-          if (q < a.Q) {
-            double g = -a.alpha[q] * (z * rk - tq) + wv[q] * (2.0 * muv[q] * rk - z * rk - tq);
-            for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-            if (lane == 0) red[wave][k][q] = g;
-          }
-        }
-      }
-      if (live) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) ppn[(long)i * a.Np] = sv[i];
-      }
-      __syncthreads();
-      if (tid < MC * a.Q) {
-        const int k = tid / a.Q, q = tid - k * a.Q;
-        if (m0 + k < a.M) {
-          const double s = red[0][k][q] + red[1][k][q] + red[2][k][q] + red[3][k][q];
-          double* dst = G + (long)(m0 + k) * a.Q + q;
-          *dst = ((grp == 0) ? 0.0 : *dst) + s;
-        }
-      }
-      __syncthreads();
+      for (int q = 0; q < QT; ++q) { zz[q] = 0.0; t[q] = 0.0; }
     }
+    // grad_Z of this lane's column and the per-point sums
+    const double* wn = WP + n * QT;                      // wave-uniform
+    const double* mun = MUP + n * QT;
+    double s0 = r;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const double zq = KEEP ? z[q] : ZP[(long)mc * QT + q];
+      const double gq = -alphaP[q] * (zq * r - t[q]) + wn[q] * (2.0 * mun[q] * r - zq * r - t[q]);
+      if (KEEP) g[q] += gq;
+      else if (active && mc < a.M && q < a.Q) { double* dst = G + (long)mc * a.Q + q; *dst = ((n == n0) ? 0.0 : *dst) + gq; }
+      const double s1 = wave_sum(zq * r), s2 = wave_sum(zq * zq * r), s3 = wave_sum(zq * t[q]);
+      if (lane == 0) { red[wave][1 + q] = s1; red[wave][1 + QT + q] = s2; red[wave][1 + 2 * QT + q] = s3; }
+    }
+    s0 = wave_sum(s0);
+    if (lane == 0) red[wave][0] = s0;
+    __syncthreads();
+    if (threadIdx.x < PW)
+      a.pp[((long)blockIdx.y * PW + threadIdx.x) * a.Np + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    __syncthreads();
+  }
+  if (KEEP && active && mc < a.M) {
+#pragma unroll
+    for (int q = 0; q < QT; ++q) if (q < a.Q) G[(long)mc * a.Q + q] = g[q];
   }
 }
 
 // per-point finish of the psi2 part from the running sums pp[n] = [sr, zr_q, z2r_q, zt_q]
 __global__ void __launch_bounds__(256) psi2_points_finish_kernel(PB2Args a) {
   __shared__ double redq[256];
-  const int PW = 3 * a.Q + 1;
   for (int q = 0; q < a.Q; ++q) {
     double ga = 0.0;
     for (long n = blockIdx.x * 256L + threadIdx.x; n < a.N; n += (long)gridDim.x * 256L) {
-      const double* ppn = a.pp + n;
-      const double sr = ppn[0], zr = ppn[(long)(1 + q) * a.Np], z2r = ppn[(long)(1 + a.QB + q) * a.Np], zt = ppn[(long)(1 + 2 * a.QB + q) * a.Np];
+      double sr = 0.0, zr = 0.0, z2r = 0.0, zt = 0.0;
+      for (int sp = 0; sp < (a.nslab + 3) / 4; ++sp) {          // one slab of sums per group of four column slabs
+        const double* ppn = a.pp + (long)sp * (3 * a.QB + 1) * a.Np + n;
+        sr += ppn[0]; zr += ppn[(long)(1 + q) * a.Np]; z2r += ppn[(long)(1 + a.QB + q) * a.Np]; zt += ppn[(long)(1 + 2 * a.QB + q) * a.Np];
+      }
       const double s = a.S[n * a.Q + q], al = a.alpha[q], w = a.Wn[n * a.Q + q], mu = a.mu[n * a.Q + q];
       const double d2 = 2.0 * al * s + 1.0;
       const double quad = 4.0 * mu * mu * sr - 8.0 * mu * zr + 2.0 * z2r + 2.0 * zt;
@@ -482,14 +323,17 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   const long Np = c->Np, Mp = c->Mp, M = c->M, Q = c->Q;
   int rc = GP_OK;
   auto A = [&](auto** p, size_t n) { if (rc == GP_OK) rc = balloc(c, p, n); };
-  c->QB = Q <= 4 ? 4 : Q <= 10 ? 10 : Q <= 16 ? 16 : Q <= 32 ? 32 : 64;
-  A(&c->LE, (size_t)Np * Mp); A(&c->LET, (size_t)Mp * Np); A(&c->Vn, (size_t)Np * Q); A(&c->Wn, (size_t)Np * Q);
-  A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB);
-  A(&c->V2T, (size_t)Np * c->QB); A(&c->WT, (size_t)Np * c->QB); A(&c->MUT, (size_t)Np * c->QB);
+  c->QB = Q <= 4 ? 4 : Q <= 10 ? 10 : Q <= 16 ? 16 : Q <= 24 ? 24 : Q <= 32 ? 32 : Q <= 52 ? 52 : 64;
+  A(&c->LE, (size_t)Np * Mp); A(&c->LET, (size_t)Np * Mp); A(&c->Vn, (size_t)Np * Q); A(&c->Wn, (size_t)Np * Q);
+  A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB); A(&c->WP, (size_t)Np * c->QB); A(&c->MUP, (size_t)Np * c->QB);
+  A(&c->alphaP, (size_t)c->QB);
   A(&c->DZ2, (size_t)M * M * Q); A(&c->lnc2h, (size_t)Np);
-  const long groups = (c->N + 255) / 256;
-  c->pb_blocks = (int)std::min<long>(groups, 2048);
-  A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q); A(&c->pp, (size_t)Np * (3 * c->QB + 1));
+  // phase-2 pair kernel: grid (point chunks, groups of four 64-column slabs); >= 64 points per workgroup, <= 2048 chunks
+  c->nslab = (int)((M + 63) / 64);
+  c->ppb = (int)std::max<long>(64, (c->N + 2047) / 2048);
+  c->pb_blocks = (int)((c->N + c->ppb - 1) / c->ppb);
+  A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q);
+  A(&c->pp, (size_t)Np * (3 * c->QB + 1) * ((c->nslab + 3) / 4));
   std::vector<int> t;
   const int Mt = (int)((M + 15) / 16);
   for (int i = 0; i < Mt; ++i) for (int j = i; j < Mt; ++j) { t.push_back(i); t.push_back(j); }
@@ -523,7 +367,8 @@ int run_generate_b(gp_ctx* c) {
   rc = run_dz2(c);
   if (rc != GP_OK) return rc;
   hipLaunchKernelGGL(b_tables_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, c->mu, c->S, c->alpha, (long)c->N, (long)c->Np, c->Q,
-                     c->sf2, c->Vn, c->Wn, c->lnc2h, c->V2P, c->QB, c->V2T, c->WT, c->MUT);
+                     c->sf2, c->Vn, c->Wn, c->lnc2h, c->V2P, c->QB, c->WP, c->MUP);
+  GP_HIP(c, hipMemcpyAsync(c->alphaP, c->alpha, (size_t)c->Q * 8, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(zpad_kernel, dim3((unsigned)(((long)c->Mp * c->QB + 255) / 256)), dim3(256), 0, c->stream, c->Z, c->M, c->Mp, c->Q, c->QB,
                      c->ZP);
   dim3 grid(c->Mp / 16, (unsigned)(c->Np / 16));
@@ -540,13 +385,17 @@ static void launch_pairs(gp_ctx* c, int S) {
 }
 
 int run_phase1_b(gp_ctx* c) {
-  int S = (int)std::max<long>(1, std::min<long>(64, std::min<long>(c->N, (4096 + c->n_ptiles - 1) / c->n_ptiles)));
+  // n-slices: many more workgroups than resident slots (256 CUs x 7) so the last round is short, >= 1024 points per slice
+  int S = (int)std::max<long>(1, std::min<long>(64, std::max<long>((4096 + c->n_ptiles - 1) / c->n_ptiles, c->N / 1024)));
+  S = (int)std::min<long>(S, c->N);
   if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
   switch (c->QB) {
     case 4: launch_pairs<4>(c, S); break;
     case 10: launch_pairs<10>(c, S); break;
     case 16: launch_pairs<16>(c, S); break;
+    case 24: launch_pairs<24>(c, S); break;
     case 32: launch_pairs<32>(c, S); break;
+    case 52: launch_pairs<52>(c, S); break;
     default: launch_pairs<64>(c, S); break;
   }
   GP_HIP(c, hipGetLastError());
@@ -555,32 +404,34 @@ int run_phase1_b(gp_ctx* c) {
   return GP_OK;
 }
 
-template <int QT, int MC>
-static void launch_rows(gp_ctx* c, const PB2Args& a, int blocks) {
-  hipLaunchKernelGGL((psi2_rows_kernel<QT, MC>), dim3(blocks), dim3(256), 0, c->stream, a, (const double*)c->ZP, (const double*)c->Bbar,
-                     (const double*)c->LET, (const double*)c->V2P);
+template <int QT, bool KEEP>
+static void launch_cols(gp_ctx* c, const PB2Args& a) {
+  hipLaunchKernelGGL((psi2_cols_kernel<QT, KEEP>), dim3(c->pb_blocks, (c->nslab + 3) / 4), dim3(256), 0, c->stream, a, (const double*)c->ZP,
+                     (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
+                     (const double*)c->alphaP);
 }
 
 int run_phase2_b(gp_ctx* c) {
   if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
   PB2Args a;
-  a.LET = c->LET; a.Vn = c->Vn; a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.DZ2 = c->DZ2; a.Z = c->Z; a.Bbar = c->Bbar; a.alpha = c->alpha;
-  a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp; a.V2P = c->V2P; a.ZP = c->ZP; a.V2T = c->V2T; a.WT = c->WT; a.MUT = c->MUT;
-  a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB;
-  const long groups = (c->N + 255) / 256;
-  a.groups_per_block = (int)((groups + c->pb_blocks - 1) / c->pb_blocks);
-  const int blocks = (int)((groups + a.groups_per_block - 1) / a.groups_per_block);
-  if (c->Q <= 4) launch_rows<4, 4>(c, a, blocks);
-  else if (c->Q <= 10) launch_rows<10, 4>(c, a, blocks);
-  else if (c->Q <= 16) launch_rows<16, 2>(c, a, blocks);
-  else if (c->Q <= 32) hipLaunchKernelGGL((psi2_rows_wide_kernel<32, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
-  else hipLaunchKernelGGL((psi2_rows_wide_kernel<64, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+  a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
+  a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
+  a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb;
+  switch (c->QB) {
+    case 4: launch_cols<4, true>(c, a); break;
+    case 10: launch_cols<10, true>(c, a); break;
+    case 16: launch_cols<16, false>(c, a); break;
+    case 24: launch_cols<24, false>(c, a); break;
+    case 32: launch_cols<32, false>(c, a); break;
+    case 52: launch_cols<52, false>(c, a); break;
+    default: launch_cols<64, false>(c, a); break;
+  }
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_points_finish_kernel, dim3(c->pb_blocks), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());
   const long MQ = (long)c->M * c->Q;
   hipLaunchKernelGGL(pb2_reduce_kernel, dim3((unsigned)std::min<long>((MQ + c->Q + 255) / 256, 1024)), dim3(256), 0, c->stream, c->Gpart,
-                     c->gapart2, blocks, c->pb_blocks, MQ, c->Q, c->grads);
+                     c->gapart2, c->pb_blocks, c->pb_blocks, MQ, c->Q, c->grads);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }

@@ -529,7 +529,8 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
   for (int am = 0; am < 4; ++am)
 #pragma unroll
     for (int bc = 0; bc < NRB; ++bc) r[am][bc] = 0.0;
-  const int crow = lane >> 2, ccg = lane & 3;                     // coalesced slab load: row, 16-column group
+  const int crow = lane & 15, ccg = lane >> 4;                    // slab load: row, 16-column group (8 consecutive lanes -> 8 rows: the
+                                                                  // 16-byte LDS stores of a lane group hit 32 distinct banks)
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;

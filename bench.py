@@ -143,7 +143,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'gp::p2_fast_kernel<6>', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / FP64_PEAK_TFLOPS, 'traffic': traffic},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
             res['cpu_baseline'] = cpu_baseline(D, M, Q, N, min(a.cpu_rows, N))
         print(json.dumps(res))
     if world > 1:

@@ -125,6 +125,7 @@ struct gp_ctx {
   double* lnc2h = nullptr;    // [Np]      1/2 ln c2_n
   double* DZ2 = nullptr;      // [M][M][Q] (z_mq - z_m'q)^2
   double* Gpart = nullptr;    // [pb_blocks][M][Q] per-block grad_Z partials of the psi2 part
+  double* Gtmp = nullptr;     // [64][M][Q] second-level grad_Z partials
   double* gapart2 = nullptr;  // [pb_blocks][Q]
   double* pp = nullptr;       // [Np][3Q+1] per-point running sums sr, zr, z2r, zt of the psi2 rows kernel
   int pb_blocks = 0;

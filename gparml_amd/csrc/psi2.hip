@@ -190,7 +190,7 @@ __global__ void fill_kernel(double* x, long n, double v) {
 struct PB2Args {
   const double* Wn; const double* mu; const double* S; const double* alpha;
   double* Gpart; double* gapart2; double* gmu; double* gS; double* pp;
-  long N, Np; int M, Mp, Q, QB, nslab, ppb;   // nslab = ceil(M/64) column slabs; ppb points per workgroup
+  long N, Np; int M, Mp, Q, QB, nslab, ppb, ngrp;   // nslab = ceil(M/64) column slabs in ngrp groups of <= 4; ppb points per workgroup
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -206,8 +206,9 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_c
   constexpr int PW = 3 * QT + 1;
   __shared__ double red[4][PW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slab = blockIdx.y * 4 + wave;
-  const bool active = slab < a.nslab;                    // idle waves (M not a multiple of 256) only join the barriers
+  const int nw = blockDim.x >> 6;                        // waves per workgroup = min(4, nslab)
+  const int slab = blockIdx.y * nw + wave;
+  const bool active = slab < a.nslab;                    // idle waves (nslab not a multiple of nw) only join the barriers
   const int mc = (active ? slab : 0) * 64 + lane;        // this lane's column m' (< Mp; columns >= M: LEA = kPadLog, ZP = 0)
   double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;    // this workgroup's grad_Z partial (rows of its slabs)
   double z[KEEP ? QT : 1], g[KEEP ? QT : 1];
@@ -263,8 +264,11 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_c
     s0 = wave_sum(s0);
     if (lane == 0) red[wave][0] = s0;
     __syncthreads();
-    if (threadIdx.x < PW)
-      a.pp[((long)blockIdx.y * PW + threadIdx.x) * a.Np + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    for (int i = threadIdx.x; i < PW; i += blockDim.x) {
+      double sum = red[0][i];
+      for (int w = 1; w < nw; ++w) sum += red[w][i];
+      a.pp[((long)blockIdx.y * PW + i) * a.Np + n] = sum;
+    }
     __syncthreads();
   }
   if (KEEP && active && mc < a.M) {
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(256) psi2_points_finish_kernel(PB2Args a) {
     double ga = 0.0;
     for (long n = blockIdx.x * 256L + threadIdx.x; n < a.N; n += (long)gridDim.x * 256L) {
       double sr = 0.0, zr = 0.0, z2r = 0.0, zt = 0.0;
-      for (int sp = 0; sp < (a.nslab + 3) / 4; ++sp) {          // one slab of sums per group of four column slabs
+      for (int sp = 0; sp < a.ngrp; ++sp) {                     // one slab of sums per group of column slabs (workgroup row)
         const double* ppn = a.pp + (long)sp * (3 * a.QB + 1) * a.Np + n;
         sr += ppn[0]; zr += ppn[(long)(1 + q) * a.Np]; z2r += ppn[(long)(1 + a.QB + q) * a.Np]; zt += ppn[(long)(1 + 2 * a.QB + q) * a.Np];
       }
@@ -299,7 +303,21 @@ __global__ void __launch_bounds__(256) psi2_points_finish_kernel(PB2Args a) {
   }
 }
 
-// grads[0:M*Q] += sum_blocks Gpart ; grads[M*Q + q] += sum_blocks gapart2
+// stage 1 of the grad_Z partial sum: tmp[s][e] = sum over the s-th share of the workgroup partials (coalesced 512-byte rows)
+__global__ void __launch_bounds__(256) pb2_reduce1_kernel(const double* __restrict__ Gpart, int nb, long E, int S2, double* __restrict__ tmp) {
+  __shared__ double red[4][64];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long e = blockIdx.x * 64L + el;
+  const int per = (nb + S2 - 1) / S2;
+  const int b0 = blockIdx.y * per, b1 = min(nb, b0 + per);
+  double s = 0.0;
+  if (e < E) for (int b = b0 + g; b < b1; b += 4) s += Gpart[(long)b * E + e];
+  red[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < E) tmp[(long)blockIdx.y * E + e] = red[0][el] + red[1][el] + red[2][el] + red[3][el];
+}
+
+// grads[0:M*Q] += sum_s tmp[s] ; grads[M*Q + q] += sum_blocks gapart2
 __global__ void __launch_bounds__(256) pb2_reduce_kernel(const double* __restrict__ Gpart, const double* __restrict__ gapart2, int nb, int nb2,
                                                          long MQ, int Q, double* __restrict__ grads) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < MQ + Q; i += (long)gridDim.x * 256L) {
@@ -310,7 +328,6 @@ __global__ void __launch_bounds__(256) pb2_reduce_kernel(const double* __restric
   }
 }
 
-// ---------------------------------------------------------------------------------------------- host side
 template <typename T>
 static int balloc(gp_ctx* c, T** p, size_t count) {
   GP_HIP(c, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
@@ -328,11 +345,11 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB); A(&c->WP, (size_t)Np * c->QB); A(&c->MUP, (size_t)Np * c->QB);
   A(&c->alphaP, (size_t)c->QB);
   A(&c->DZ2, (size_t)M * M * Q); A(&c->lnc2h, (size_t)Np);
-  // phase-2 pair kernel: grid (point chunks, groups of four 64-column slabs); >= 64 points per workgroup, <= 2048 chunks
+  // phase-2 pair kernel: grid (point chunks, groups of <= 4 64-column slabs); >= 16 points per workgroup, <= 4096 chunks
   c->nslab = (int)((M + 63) / 64);
-  c->ppb = (int)std::max<long>(64, (c->N + 2047) / 2048);
+  c->ppb = (int)std::max<long>(16, (c->N + 4095) / 4096);
   c->pb_blocks = (int)((c->N + c->ppb - 1) / c->ppb);
-  A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q);
+  A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q); A(&c->Gtmp, (size_t)64 * M * Q);
   A(&c->pp, (size_t)Np * (3 * c->QB + 1) * ((c->nslab + 3) / 4));
   std::vector<int> t;
   const int Mt = (int)((M + 15) / 16);
@@ -406,7 +423,8 @@ int run_phase1_b(gp_ctx* c) {
 
 template <int QT, bool KEEP>
 static void launch_cols(gp_ctx* c, const PB2Args& a) {
-  hipLaunchKernelGGL((psi2_cols_kernel<QT, KEEP>), dim3(c->pb_blocks, (c->nslab + 3) / 4), dim3(256), 0, c->stream, a, (const double*)c->ZP,
+  const int nw = std::min(4, c->nslab);
+  hipLaunchKernelGGL((psi2_cols_kernel<QT, KEEP>), dim3(c->pb_blocks, (c->nslab + nw - 1) / nw), dim3(64 * nw), 0, c->stream, a, (const double*)c->ZP,
                      (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
                      (const double*)c->alphaP);
 }
@@ -416,7 +434,7 @@ int run_phase2_b(gp_ctx* c) {
   PB2Args a;
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
-  a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb;
+  a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb; a.ngrp = (c->nslab + std::min(4, c->nslab) - 1) / std::min(4, c->nslab);
   switch (c->QB) {
     case 4: launch_cols<4, true>(c, a); break;
     case 10: launch_cols<10, true>(c, a); break;
@@ -427,11 +445,14 @@ int run_phase2_b(gp_ctx* c) {
     default: launch_cols<64, false>(c, a); break;
   }
   GP_HIP(c, hipGetLastError());
-  hipLaunchKernelGGL(psi2_points_finish_kernel, dim3(c->pb_blocks), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(psi2_points_finish_kernel, dim3((unsigned)std::min<long>(c->pb_blocks, 256)), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());
   const long MQ = (long)c->M * c->Q;
-  hipLaunchKernelGGL(pb2_reduce_kernel, dim3((unsigned)std::min<long>((MQ + c->Q + 255) / 256, 1024)), dim3(256), 0, c->stream, c->Gpart,
-                     c->gapart2, c->pb_blocks, c->pb_blocks, MQ, c->Q, c->grads);
+  const int S2 = std::max(1, std::min(64, c->pb_blocks / 16));
+  hipLaunchKernelGGL(pb2_reduce1_kernel, dim3((unsigned)((MQ + 63) / 64), S2), dim3(256), 0, c->stream, c->Gpart, c->pb_blocks, MQ, S2, c->Gtmp);
+  const int fin_blocks = (int)std::min<long>(c->pb_blocks, 256);      // psi2_points_finish_kernel's grid (one gapart2 row per workgroup)
+  hipLaunchKernelGGL(pb2_reduce_kernel, dim3((unsigned)std::min<long>((MQ + c->Q + 255) / 256, 1024)), dim3(256), 0, c->stream, c->Gtmp,
+                     c->gapart2, S2, fin_blocks, MQ, c->Q, c->grads);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }

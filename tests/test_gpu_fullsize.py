@@ -1,0 +1,88 @@
+"""Size-independent properties at BASELINE.json's headline size (configs[2]: N=1e6, D=100, M=512, Q=10), where no CPU
+oracle finishes in test time: (1) the map/reduce identity -- one 1e6-point shard equals two shards reduced through the
+packed device buffers, for the bound and every gradient; (2) a directional central finite difference of the bound
+against the analytic gradient (the check test.py:36-94 makes per coordinate).  Regime B at a reduced N (the pair kernels
+cost 0.5 s per 1e6 points)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic(N, D, M, Q, regime):
+    rs = np.random.RandomState(0)
+    X = rs.randn(N, Q)
+    W = np.random.RandomState(1234).randn(Q, D)
+    Y = np.sin(X.dot(W)) + 0.1 * rs.randn(N, D)
+    X_mu = X + 0.05 * rs.randn(N, Q)
+    X_S = np.zeros((N, Q)) if regime == 'A' else rs.uniform(0.05, 0.55, size=(N, Q))
+    rz = np.random.RandomState(1)
+    Z = np.random.RandomState(2).randn(4 * M, Q)[rz.permutation(4 * M)[:M]] + 0.05 * rz.randn(M, Q)
+    return dict(Y=Y, X_mu=X_mu, X_S=X_S, Z=Z, sf2=1.0, alpha=np.full(Q, 0.3), beta=10.0)
+
+
+def _eval_sharded(d, N, D, M, Q, cuts, emb, Z=None, sf2=None, alpha=None, beta=None):
+    from gparml_amd.engine import ShardEngine
+    Z = d['Z'] if Z is None else Z
+    sf2 = d['sf2'] if sf2 is None else sf2
+    alpha = d['alpha'] if alpha is None else alpha
+    beta = d['beta'] if beta is None else beta
+    engines = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e = ShardEngine(b - a, D, M, Q)
+        e.upload_shard(d['Y'][a:b], d['X_mu'][a:b], d['X_S'][a:b])
+        e.set_globals(Z, sf2, alpha, beta, N_global=N)
+        engines.append(e)
+    return engines
+
+
+def _run(engines, emb):
+    for e in engines:
+        e.phase1()
+    root = engines[0]
+    for e in engines[1:]:
+        root.combine(e, 'stats', 'add')
+    for e in engines[1:]:
+        e.combine(root, 'stats', 'copy')
+    for e in engines:
+        e.global_step()
+        e.phase2(emb)
+    for e in engines[1:]:
+        root.combine(e, 'grads', 'add')
+    out = root.finish()
+    if emb:
+        out['grad_X_mu'] = np.concatenate([e.download('GRAD_X_MU') for e in engines])
+        out['grad_X_S'] = np.concatenate([e.download('GRAD_X_S') for e in engines])
+    return out
+
+
+@pytest.mark.parametrize('N,D,M,Q,regime', [(1000000, 100, 512, 10, 'A'), (60000, 20, 512, 10, 'B')])
+def test_map_reduce_identity_and_directional_derivative(N, D, M, Q, regime):
+    emb = regime == 'B'
+    d = _synthetic(N, D, M, Q, regime)
+    one = _eval_sharded(d, N, D, M, Q, [0, N], emb)
+    ref = _run(one, emb)
+    two = _eval_sharded(d, N, D, M, Q, [0, N // 3 + 17, N], emb)
+    out = _run(two, emb)
+    for e in two:
+        e.close()
+    assert_close(out['F'], ref['F'], 1e-11, what='F (2 shards vs 1)')
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta') + (('grad_X_mu', 'grad_X_S') if emb else ()):
+        assert_close(out[k], ref[k], 1e-8, what=k + ' (2 shards vs 1)')
+    # directional derivative along a random direction of (Z, sf2, alpha, beta), central difference
+    rs = np.random.RandomState(5)
+    dZ, ds, da, db = rs.randn(M, Q), rs.randn(), rs.randn(Q), rs.randn()
+    scale = 1e-6
+    ana = float(np.sum(ref['grad_Z'] * dZ) + ref['grad_sf2'] * ds * d['sf2'] + np.sum(ref['grad_alpha'] * da * d['alpha'])
+                + ref['grad_beta'] * db * d['beta'])
+    Fs = []
+    eng = one[0]
+    for sgn in (+1.0, -1.0):
+        h = sgn * scale
+        eng.set_globals(d['Z'] + h * dZ, d['sf2'] * (1 + h * ds), d['alpha'] * (1 + h * da), d['beta'] * (1 + h * db), N_global=N)
+        Fs.append(_run([eng], False)['F'])
+    eng.close()
+    fd = (Fs[0] - Fs[1]) / (2 * scale)
+    assert abs(fd - ana) <= 2e-5 * abs(ana) + 1e-6 * abs(ref['F']) * 1e-3, 'directional derivative: fd %.10e vs analytic %.10e' % (fd, ana)

@@ -76,10 +76,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    # test hooks (tests/test_gpu_bench_ranks.py): several ranks on ONE device over gloo exercise the N>1 code path on a 1-GPU box
+    if os.environ.get('GPARML_BENCH_ONE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get('GPARML_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
     dev = torch.device('cuda', local_rank)
 
     from gparml_amd.engine import ShardEngine

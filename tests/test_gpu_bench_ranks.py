@@ -1,0 +1,80 @@
+"""bench.py's N>1 path on a 1-GPU box: two ranks share device 0 and reduce over gloo (test hooks GPARML_BENCH_*), so the
+barrier / max-over-ranks timing / rank-0 JSON line and the two per-evaluation all-reduces on the library's device buffers
+run exactly as under `torch.distributed.run --nproc-per-node N` with RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_one_device():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GPARML_BENCH_ONE_DEVICE='1', GPARML_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--N', '30000', '--D', '12', '--M', '96', '--Q', '5']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['steps'] == 3 and res['scaling'] == 'weak' and res['value'] > 0
+    assert 'roofline' in res and 'cpu_baseline' not in res            # CPU baseline: rank 0 at N=1 only
+    # the same workload on one rank: the global bound of two different shards differs, but the per-rank work is the same
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--N', '30000',
+                         '--D', '12', '--M', '96', '--Q', '5', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][0])
+    assert one['n_gpus'] == 1
+
+
+RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from gparml_amd.engine import ShardEngine
+from gparml_amd.dist import DistributedEvaluator
+from oracle import factorised as Fz
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+N, D, M, Q = 1200, 6, 70, 4
+for regime in ('A', 'B'):
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=21, zseed=22, alpha_value=0.5)
+    cut = [0, 500, N]
+    a, b = cut[rank], cut[rank + 1]
+    eng = ShardEngine(b - a, D, M, Q)
+    eng.upload_shard(d['Y'][a:b], d['X_mu'][a:b], d['X_S'][a:b])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
+    out = DistributedEvaluator(eng, device=torch.device('cuda', 0)).evaluate(regime == 'B')
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+    assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F']), (out['F'], ref['F'])
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'):
+        assert np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) <= 1e-5 * np.max(np.abs(ref[k])), k
+    if regime == 'B':
+        for k, name in (('grad_X_mu', 'GRAD_X_MU'), ('grad_X_S', 'GRAD_X_S')):
+            g = eng.download(name)
+            assert np.max(np.abs(g - ref[k][a:b])) <= 1e-5 * np.max(np.abs(ref[k])), k
+    eng.close()
+dist.destroy_process_group()
+print('RANK_OK', rank)
+"""
+
+
+def test_two_rank_evaluation_matches_the_oracle(tmp_path):
+    """Two processes, one shard each (both on device 0, gloo): bound and every gradient equal the oracle's on the
+    concatenated data -- the all-reduce of the packed device buffers is the statistics_reducer (local_MapReduce.py:250-277)."""
+    script = tmp_path / 'rank_script.py'
+    script.write_text(RANK_SCRIPT % {'root': ROOT})
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and r.stdout.count('RANK_OK') == 2, r.stdout[-2000:] + r.stderr[-4000:]

@@ -120,6 +120,8 @@ struct gp_ctx {
   double* WP = nullptr;       // [Np][QB]  w_nq, zero-padded
   double* MUP = nullptr;      // [Np][QB]  mu_nq, zero-padded
   double* alphaP = nullptr;   // [QB]      alpha, zero-padded
+  double* Z1P = nullptr;      // [Mp][QB]  Z with a column of ones at index Q (only meaningful when QB > Q)
+  bool b_mfma = false;        // regime-B phase 2 on the matrix core (Q >= 17)
   double* ZP = nullptr;       // [Mp][QB]  Z zero-padded (rows >= M and columns >= Q are zero)
   int QB = 0;                 // 4, 10, 16, 32 or 64: smallest instantiated width >= Q
   double* lnc2h = nullptr;    // [Np]      1/2 ln c2_n

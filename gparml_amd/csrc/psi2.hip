@@ -71,11 +71,14 @@ __global__ void __launch_bounds__(256) dz2_kernel(const double* __restrict__ Z, 
   }
 }
 
-__global__ void __launch_bounds__(256) zpad_kernel(const double* __restrict__ Z, int M, int Mp, int Q, int QB, double* __restrict__ ZP) {
+__global__ void __launch_bounds__(256) zpad_kernel(const double* __restrict__ Z, int M, int Mp, int Q, int QB, double* __restrict__ ZP,
+                                                    double* __restrict__ Z1P) {
   const long total = (long)Mp * QB;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int q = (int)(i % QB), m = (int)(i / QB);
-    ZP[i] = (m < M && q < Q) ? Z[(long)m * Q + q] : 0.0;
+    const double z = (m < M && q < Q) ? Z[(long)m * Q + q] : 0.0;
+    ZP[i] = z;
+    Z1P[i] = (q == Q) ? 1.0 : z;          // Z with a column of ones at index Q (the MFMA kernel's row-sum column)
   }
 }
 
@@ -277,6 +280,191 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_c
   }
 }
 
+// ---- wide latent spaces (Q >= 25): the same column ownership on the matrix core.  A row of z_m no longer fits the scalar
+// register file (2 QT SGPRs), so the two Q-contractions become 4x4x4 FP64 MFMAs fed from LDS:
+//   GEMM1  E[m, m'] = sum_q Z1[m, q] * ZZ_n[m', q]            (ZZ_n = -2 V_n o Z, zero beyond Q)
+//   T = Bbar o exp(E + LEA[n, m] + LEA[n, m'])                 (VALU, on the accumulator registers)
+//   GEMM2  t[m', q] = sum_m T[m, m'] * Z1[m, q]                (Z1 = Z with a column of ones at index Q: that column is r)
+// A workgroup = 4 waves x 16 columns, walks the rows in strips of 16 (staged once in LDS for the four waves).  One
+// instruction is a 16 x 4 output tile (mma_f64.h); the T registers are used AS the A operand of GEMM2: the operand map
+// A_b[i = l&3][k = l>>4] reads a result register D_b[i = l>>4][j = l&3] transposed, which is exactly T^T restricted to the
+// block's four rows, so no LDS round trip is needed.  Each of the four blocks then holds the partial sum over its own
+// row quad; they are added once per point.  Same pipe as the VALU: the gain is operand delivery.
+template <int QT>
+__global__ void __launch_bounds__(256, 1) psi2_cols_mfma_kernel(PB2Args a, const double* __restrict__ Z1P, const double* __restrict__ Bbar,
+                                                                const double* __restrict__ LEA, const double* __restrict__ V2P,
+                                                                const double* __restrict__ WP, const double* __restrict__ MUP,
+                                                                const double* __restrict__ alphaP) {
+  constexpr int NQ = QT / 4;                       // q quads
+  constexpr int LDZ = QT <= 32 ? 34 : 66;          // LDS row stride (== 2 mod 32: the A-operand read of a strip is conflict-free)
+  constexpr int PW = 3 * QT + 1;
+  constexpr int RB = 4, SR = 16 * RB;              // a strip = RB row blocks of 16 = 64 rows
+  extern __shared__ double smem[];
+  double* zs = smem;                               // [2][SR][LDZ]  row strips of Z1
+  double* zzs = zs + 2 * SR * LDZ;                 // [4][16][LDZ]  per wave: ZZ_n of its 16 columns
+  double* lrow = zzs + 4 * 16 * LDZ;               // [Mp]          LEA[n, :]
+  double* red = lrow + a.Mp;                       // [4][PW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
+  const int c0 = blockIdx.y * 64 + wave * 16;      // first column of this wave (< Mp)
+  double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;
+  double* zzw = zzs + wave * 16 * LDZ;
+  const long n0 = (long)blockIdx.x * a.ppb, n1 = min(a.N, n0 + a.ppb);
+  const int nstrip = (a.M + SR - 1) / SR;          // 64 * nstrip <= Mp
+  // strip staging: SR rows x QT doubles are contiguous in Z1P; thread t moves elements t, t+256, ...
+  constexpr int SE = SR * QT, SPT = (SE + 255) / 256;
+  const int aofs = (4 * lb + li) * LDZ + lk;       // A_b[i][k]  = Z1[r0 + 16 rb + 4b + i][4 k4 + k]   (+ 16 rb LDZ + 4 k4)
+  const int bofs = li * LDZ + lk;                  // B[k][j]    = ZZ[c0 + 4 cq + j][4 k4 + k]          (+ 4 cq LDZ + 4 k4)
+  const int b2ofs = (4 * lb + lk) * LDZ + li;      // B2_b[k][j] = Z1[r0 + 16 rb + 4b + k][4 qq + j]   (+ 16 rb LDZ + 4 qq)
+  for (long n = n0; n < n1; ++n) {
+    // ---- per-point operands
+    for (int m = tid; m < a.Mp; m += 256) lrow[m] = LEA[n * a.Mp + m];
+    for (int e = lane; e < 16 * QT; e += 64) {
+      const int j = e / QT, q = e - j * QT;
+      zzw[j * LDZ + q] = V2P[n * QT + q] * Z1P[(long)(c0 + j) * QT + q];
+    }
+    double lcol[4];
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) lcol[cq] = LEA[n * a.Mp + c0 + 4 * cq + li];
+    double tacc[4][NQ];
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) tacc[cq][qq] = 0.0;
+    double stage[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; stage[i] = e < SE ? Z1P[e] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; if (e < SE) zs[(e / QT) * LDZ + (e % QT)] = stage[i]; }
+    __syncthreads();
+    for (int s = 0; s < nstrip; ++s) {
+      const double* zb = zs + (s & 1) * SR * LDZ;
+      const int r0 = SR * s;
+      if (s + 1 < nstrip) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; stage[i] = e < SE ? Z1P[(long)(r0 + SR) * QT + e] : 0.0; }
+      }
+      // Bbar for the 16 result registers: row r0 + 16 rb + 4 lb + lk, column c0 + 4 cq + li
+      double bb[RB][4];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const double* brow = Bbar + (long)(r0 + 16 * rb + 4 * lb + lk) * a.Mp + c0 + li;
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) bb[rb][cq] = brow[4 * cq];
+      }
+      // GEMM1 (operands of step k4+1 are read while the 16 MFMAs of step k4 execute)
+      double E[RB][4];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) E[rb][cq] = 0.0;
+      double av[2][RB], bv[2][4];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) av[0][rb] = zb[aofs + 16 * rb * LDZ];
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) bv[0][cq] = zzw[bofs + 4 * cq * LDZ];
+#pragma unroll
+      for (int k4 = 0; k4 < NQ; ++k4) {
+        const int cur = k4 & 1, nxt = cur ^ 1;
+        if (k4 + 1 < NQ) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) av[nxt][rb] = zb[aofs + 16 * rb * LDZ + 4 * (k4 + 1)];
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq) bv[nxt][cq] = zzw[bofs + 4 * cq * LDZ + 4 * (k4 + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq) E[rb][cq] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cur][rb], bv[cur][cq], E[rb][cq], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // T = Bbar o exp(E + LEA[n, row] + LEA[n, col]) on the result registers
+      double b2[2][RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) b2[0][rb] = zb[b2ofs + 16 * rb * LDZ];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const double lr = lrow[r0 + 16 * rb + 4 * lb + lk];
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) E[rb][cq] = bb[rb][cq] * fexp(E[rb][cq] + lr + lcol[cq]);
+      }
+      // GEMM2: tacc[cq][qq] += sum_rb T[rb][cq]^T . B2[rb][qq]
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) {
+        const int cur = qq & 1, nxt = cur ^ 1;
+        if (qq + 1 < NQ) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) b2[nxt][rb] = zb[b2ofs + 16 * rb * LDZ + 4 * (qq + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq) tacc[cq][qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(E[rb][cq], b2[cur][rb], tacc[cq][qq], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (s + 1 < nstrip) {
+        double* zn = zs + ((s + 1) & 1) * SR * LDZ;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; if (e < SE) zn[(e / QT) * LDZ + (e % QT)] = stage[i]; }
+      }
+      __syncthreads();
+    }
+    // ---- per point: add the four row-quad partials (lanes that differ in bits 2,3), then lane (lk, li) holds
+    //      t[column c0 + 4 cq + lk][q = 4 qq + li] in every block
+    const int Qq = a.Q >> 2, Qj = a.Q & 3;          // the ones column (index Q) sits in quad Qq, position Qj
+    double rcol[4];
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) {
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) {
+        double v = tacc[cq][qq];
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        tacc[cq][qq] = v;
+      }
+      double rv = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) if (qq == Qq) rv = tacc[cq][qq];
+      rcol[cq] = __shfl(rv, (lane & ~3) | Qj);     // r of column c0 + 4 cq + lk, for every li
+    }
+    double s0 = 0.0;
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) s0 += rcol[cq];
+    s0 += __shfl_xor(s0, 16);
+    s0 += __shfl_xor(s0, 32);                      // sum over the wave's 16 columns (identical in every lane)
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int q = 4 * qq + li;
+      const double al = alphaP[q], wq = WP[n * QT + q], muq = MUP[n * QT + q];
+      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) {
+        const int col = c0 + 4 * cq + lk;
+        const double zq = (q < a.Q) ? Z1P[(long)col * QT + q] : 0.0;      // the ones column is not a latent dimension
+        const double r = rcol[cq], t = (q < a.Q) ? tacc[cq][qq] : 0.0;
+        // grad_Z of (col, q) accumulates in this workgroup's partial (26 KB per workgroup: it lives in L2); the four
+        // blocks hold identical totals, block 0 writes
+        if (lb == 0 && col < a.M && q < a.Q) {
+          double* dst = G + (long)col * a.Q + q;
+          *dst = ((n == n0) ? 0.0 : *dst) - al * (zq * r - t) + wq * (2.0 * muq * r - zq * r - t);
+        }
+        s1 = fma(zq, r, s1); s2 = fma(zq * zq, r, s2); s3 = fma(zq, t, s3);
+      }
+      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+      s3 += __shfl_xor(s3, 16); s3 += __shfl_xor(s3, 32);
+      if (lane < 4) { red[wave * PW + 1 + q] = s1; red[wave * PW + 1 + QT + q] = s2; red[wave * PW + 1 + 2 * QT + q] = s3; }
+    }
+    if (lane == 0) red[wave * PW] = s0;
+    __syncthreads();
+    for (int i = tid; i < PW; i += 256)
+      a.pp[((long)blockIdx.y * PW + i) * a.Np + n] = red[i] + red[PW + i] + red[2 * PW + i] + red[3 * PW + i];
+    __syncthreads();
+  }
+}
+
 // per-point finish of the psi2 part from the running sums pp[n] = [sr, zr_q, z2r_q, zt_q]
 __global__ void __launch_bounds__(256) psi2_points_finish_kernel(PB2Args a) {
   __shared__ double redq[256];
@@ -340,9 +528,11 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   const long Np = c->Np, Mp = c->Mp, M = c->M, Q = c->Q;
   int rc = GP_OK;
   auto A = [&](auto** p, size_t n) { if (rc == GP_OK) rc = balloc(c, p, n); };
-  c->QB = Q <= 4 ? 4 : Q <= 10 ? 10 : Q <= 16 ? 16 : Q <= 24 ? 24 : Q <= 32 ? 32 : Q <= 52 ? 52 : 64;
+  // compiled latent widths; from 25 on the phase-2 kernel is the MFMA one and needs a spare column (QB > Q) for the ones
+  c->QB = Q <= 4 ? 4 : Q <= 10 ? 10 : Q <= 16 ? 16 : Q <= 24 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : 64;
+  c->b_mfma = Q >= 25 && Q < c->QB;
   A(&c->LE, (size_t)Np * Mp); A(&c->LET, (size_t)Np * Mp); A(&c->Vn, (size_t)Np * Q); A(&c->Wn, (size_t)Np * Q);
-  A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB); A(&c->WP, (size_t)Np * c->QB); A(&c->MUP, (size_t)Np * c->QB);
+  A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB); A(&c->Z1P, (size_t)Mp * c->QB); A(&c->WP, (size_t)Np * c->QB); A(&c->MUP, (size_t)Np * c->QB);
   A(&c->alphaP, (size_t)c->QB);
   A(&c->DZ2, (size_t)M * M * Q); A(&c->lnc2h, (size_t)Np);
   // phase-2 pair kernel: grid (point chunks, groups of <= 4 64-column slabs); >= 16 points per workgroup, <= 4096 chunks
@@ -350,7 +540,7 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   c->ppb = (int)std::max<long>(16, (c->N + 4095) / 4096);
   c->pb_blocks = (int)((c->N + c->ppb - 1) / c->ppb);
   A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q); A(&c->Gtmp, (size_t)64 * M * Q);
-  A(&c->pp, (size_t)Np * (3 * c->QB + 1) * ((c->nslab + 3) / 4));
+  A(&c->pp, (size_t)Np * (3 * c->QB + 1) * (c->b_mfma ? c->nslab : (c->nslab + 3) / 4));
   std::vector<int> t;
   const int Mt = (int)((M + 15) / 16);
   for (int i = 0; i < Mt; ++i) for (int j = i; j < Mt; ++j) { t.push_back(i); t.push_back(j); }
@@ -387,7 +577,7 @@ int run_generate_b(gp_ctx* c) {
                      c->sf2, c->Vn, c->Wn, c->lnc2h, c->V2P, c->QB, c->WP, c->MUP);
   GP_HIP(c, hipMemcpyAsync(c->alphaP, c->alpha, (size_t)c->Q * 8, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(zpad_kernel, dim3((unsigned)(((long)c->Mp * c->QB + 255) / 256)), dim3(256), 0, c->stream, c->Z, c->M, c->Mp, c->Q, c->QB,
-                     c->ZP);
+                     c->ZP, c->Z1P);
   dim3 grid(c->Mp / 16, (unsigned)(c->Np / 16));
   hipLaunchKernelGGL(b_le_kernel, grid, dim3(256), 0, c->stream, c->mu, c->Wn, c->Vn, c->lnc2h, c->Z, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
                      c->LE, c->LET);
@@ -429,12 +619,38 @@ static void launch_cols(gp_ctx* c, const PB2Args& a) {
                      (const double*)c->alphaP);
 }
 
+template <int QT>
+static int launch_cols_mfma(gp_ctx* c, const PB2Args& a) {
+  constexpr int LDZ = QT <= 32 ? 34 : 66;
+  const size_t smem = ((size_t)(2 * 64 + 4 * 16) * LDZ + c->Mp + 4 * (3 * QT + 1)) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_cols_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (smem > 160 * 1024) return fail(c, GP_ERR_UNSUPPORTED, "regime B, Q >= 25: M = %d needs %zu bytes of LDS", c->M, smem);
+  hipLaunchKernelGGL((psi2_cols_mfma_kernel<QT>), dim3(c->pb_blocks, c->nslab), dim3(256), smem, c->stream, a, (const double*)c->Z1P,
+                     (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
+                     (const double*)c->alphaP);
+  return GP_OK;
+}
+
 int run_phase2_b(gp_ctx* c) {
   if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
   PB2Args a;
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
   a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb; a.ngrp = (c->nslab + std::min(4, c->nslab) - 1) / std::min(4, c->nslab);
+  if (c->b_mfma) {
+    a.ngrp = c->nslab;
+    int rc = GP_OK;
+    switch (c->QB) {
+      case 32: rc = launch_cols_mfma<32>(c, a); break;
+      case 52: rc = launch_cols_mfma<52>(c, a); break;
+      default: rc = launch_cols_mfma<64>(c, a); break;
+    }
+    if (rc != GP_OK) return rc;
+  } else
   switch (c->QB) {
     case 4: launch_cols<4, true>(c, a); break;
     case 10: launch_cols<10, true>(c, a); break;

@@ -5,8 +5,8 @@ TAG=$1; KEY=$2; shift; shift
 O=$R/gpurun_out/pmc_$TAG
 mkdir -p $O
 run() { tag=$1; shift; rocprofv3 --kernel-trace --pmc $PMC -d $O/$tag -o $tag --output-format csv -- python3 "$@" > $O/$tag.log 2>&1; }
-PMC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" run sq1 "$@"
-PMC="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_WAVES" run sq2 "$@"
+PMC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" run sq1 "$@"
+PMC="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES" run sq2 "$@"
 PMC="FETCH_SIZE" run fetch "$@"
 python3 - <<PY
 import csv, collections, glob

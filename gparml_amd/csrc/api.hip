@@ -167,6 +167,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);
   if (c->ptiles) (void)hipFree(c->ptiles);
+  if (c->tiles64) (void)hipFree(c->tiles64);
   if (c->bmap) (void)hipFree(c->bmap);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;

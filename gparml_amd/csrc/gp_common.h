@@ -134,6 +134,8 @@ struct gp_ctx {
   int nslab = 0, ppb = 0;     // regime-B phase-2 pair kernel: 64-column slabs of M, points per workgroup
   int* ptiles = nullptr;      // upper-triangular 16x16 tile table for the psi2 pair kernel
   int n_ptiles = 0;
+  int* tiles64 = nullptr;     // upper-triangular 64x64 tile table for the MFMA pair kernel (wide latent spaces)
+  int n_tiles64 = 0;
   // CG vectors (resident): grad_latest/new/old (2,N,Q) each
   double* g_latest = nullptr;
   double* g_new = nullptr;

@@ -171,6 +171,115 @@ __global__ void __launch_bounds__(256) psi2_reduce_kernel(const double* __restri
   }
 }
 
+// ---- wide latent spaces (Q >= 25): phase 1 on the matrix core.  A workgroup owns a 64 x 64 tile (I <= J) of Psi2 and an
+// n-slice; its four waves take 16 columns each.  Per point: E = Z_I . ZZ_n(J)^T (K = QT) by 4x4x4 MFMAs (rows from LDS,
+// staged once per workgroup; the wave's ZZ_n written to its own LDS slab per point), then acc += exp(E + LEA[n,m] + LEA[n,m'])
+// on the result registers.  The accumulators stay in registers for the whole slice.
+template <int QT>
+__global__ void __launch_bounds__(256, 2) psi2_pairs_mfma_kernel(const double* __restrict__ LEA, const double* __restrict__ V2P,
+                                                                 const double* __restrict__ ZP, const int* __restrict__ tiles64, long N, int Mp,
+                                                                 int S, double* __restrict__ part, int T) {
+  constexpr int NQ = QT / 4, LDZ = QT <= 32 ? 34 : 66, ZPL = (16 * QT + 63) / 64;
+  __shared__ double zr[64 * LDZ];                  // rows of tile I (the A operand), fixed
+  __shared__ double zzs[4][16 * LDZ];              // per wave: ZZ_n of its 16 columns (written and read by that wave only, in order)
+  const int tile = blockIdx.x, slice = blockIdx.y;
+  const int I = tiles64[2 * tile], J = tiles64[2 * tile + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
+  const int r0 = 64 * I, c0 = 64 * J + 16 * wave;
+  for (int e = tid; e < 64 * QT; e += 256) zr[(e / QT) * LDZ + (e % QT)] = ZP[(long)r0 * QT + e];
+  // this lane's share of the wave's 16 x QT column block of Z (element e = lane + 64 i)
+  double zc[ZPL];
+#pragma unroll
+  for (int i = 0; i < ZPL; ++i) { const int e = lane + 64 * i; zc[i] = e < 16 * QT ? ZP[(long)c0 * QT + e] : 0.0; }
+  __syncthreads();
+  const long per = (N + S - 1) / S;
+  const long na = slice * per, nb = min(N, na + per);
+  double acc[4][4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) acc[rb][cq] = 0.0;
+  const int aofs = (4 * lb + li) * LDZ + lk, bofs = li * LDZ + lk;
+  // operands of the first point
+  double v2[ZPL], lr[4], lc[4];
+  if (na < nb) {
+#pragma unroll
+    for (int i = 0; i < ZPL; ++i) { const int e = lane + 64 * i; v2[i] = e < 16 * QT ? V2P[na * QT + (e % QT)] : 0.0; }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) lr[rb] = LEA[na * Mp + r0 + 16 * rb + 4 * lb + lk];
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) lc[cq] = LEA[na * Mp + c0 + 4 * cq + li];
+  }
+  for (long n = na; n < nb; ++n) {
+    double* zzw = zzs[wave];
+#pragma unroll
+    for (int i = 0; i < ZPL; ++i) { const int e = lane + 64 * i; if (e < 16 * QT) zzw[(e / QT) * LDZ + (e % QT)] = v2[i] * zc[i]; }
+    double lrc[4], lcc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lrc[k] = lr[k]; lcc[k] = lc[k]; }
+    if (n + 1 < nb) {                              // the next point's operands travel while this point computes
+#pragma unroll
+      for (int i = 0; i < ZPL; ++i) { const int e = lane + 64 * i; v2[i] = e < 16 * QT ? V2P[(n + 1) * QT + (e % QT)] : 0.0; }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) lr[rb] = LEA[(n + 1) * Mp + r0 + 16 * rb + 4 * lb + lk];
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) lc[cq] = LEA[(n + 1) * Mp + c0 + 4 * cq + li];
+    }
+    double E[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) E[rb][cq] = 0.0;
+    double av[2][4], bv[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) av[0][rb] = zr[aofs + 16 * rb * LDZ];
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) bv[0][cq] = zzw[bofs + 4 * cq * LDZ];
+#pragma unroll
+    for (int k4 = 0; k4 < NQ; ++k4) {
+      const int cur = k4 & 1, nxt = cur ^ 1;
+      if (k4 + 1 < NQ) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) av[nxt][rb] = zr[aofs + 16 * rb * LDZ + 4 * (k4 + 1)];
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) bv[nxt][cq] = zzw[bofs + 4 * cq * LDZ + 4 * (k4 + 1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) E[rb][cq] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cur][rb], bv[cur][cq], E[rb][cq], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) acc[rb][cq] += fexp(E[rb][cq] + lrc[rb] + lcc[cq]);
+  }
+  // partial tile of this slice, in the register layout: element (rb, cq) of lane l is row 16 rb + 4 lb + lk, column 16 wave + 4 cq + li
+  double* dst = part + ((long)slice * T + tile) * 4096;
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) dst[(16 * rb + 4 * lb + lk) * 64 + 16 * wave + 4 * cq + li] = acc[rb][cq];
+}
+
+__global__ void __launch_bounds__(256) psi2_reduce64_kernel(const double* __restrict__ part, const int* __restrict__ tiles64, int T, int S,
+                                                            int M, int Mp, double* __restrict__ Psi2) {
+  const int tile = blockIdx.x;
+  const int I = tiles64[2 * tile], J = tiles64[2 * tile + 1];
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    const int m1 = 64 * I + (e >> 6), m2 = 64 * J + (e & 63);
+    double s = 0.0;
+    for (int sl = 0; sl < S; ++sl) s += part[((long)sl * T + tile) * 4096 + e];
+    if (m1 < M && m2 < M && (I != J || m2 >= m1)) {
+      Psi2[(long)m1 * Mp + m2] = s;
+      Psi2[(long)m2 * Mp + m1] = s;
+    }
+  }
+}
+
 // zero the M x M block (and pads) of Psi2 before the pair reduce writes it
 __global__ void fill_kernel(double* x, long n, double v) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] = v;
@@ -291,14 +400,15 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_c
 // block's four rows, so no LDS round trip is needed.  Each of the four blocks then holds the partial sum over its own
 // row quad; they are added once per point.  Same pipe as the VALU: the gain is operand delivery.
 template <int QT>
-__global__ void __launch_bounds__(256, 1) psi2_cols_mfma_kernel(PB2Args a, const double* __restrict__ Z1P, const double* __restrict__ Bbar,
+__global__ void __launch_bounds__(256, 2) psi2_cols_mfma_kernel(PB2Args a, const double* __restrict__ Z1P, const double* __restrict__ Bbar,
                                                                 const double* __restrict__ LEA, const double* __restrict__ V2P,
                                                                 const double* __restrict__ WP, const double* __restrict__ MUP,
                                                                 const double* __restrict__ alphaP) {
   constexpr int NQ = QT / 4;                       // q quads
-  constexpr int LDZ = QT <= 32 ? 34 : 66;          // LDS row stride (== 2 mod 32: the A-operand read of a strip is conflict-free)
+  constexpr int LDZ = QT + 2;                      // LDS row stride: (QT+2)/2 is odd for QT = 32, 52, 64, so the 16 rows of an A-operand
+                                                   // read land on 16 distinct even bank pairs (conflict-free)
   constexpr int PW = 3 * QT + 1;
-  constexpr int RB = 4, SR = 16 * RB;              // a strip = RB row blocks of 16 = 64 rows
+  constexpr int RB = 2, SR = 16 * RB;              // a strip = RB row blocks of 16 = 32 rows (two workgroups per CU fit the LDS)
   extern __shared__ double smem[];
   double* zs = smem;                               // [2][SR][LDZ]  row strips of Z1
   double* zzs = zs + 2 * SR * LDZ;                 // [4][16][LDZ]  per wave: ZZ_n of its 16 columns
@@ -546,11 +656,17 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   for (int i = 0; i < Mt; ++i) for (int j = i; j < Mt; ++j) { t.push_back(i); t.push_back(j); }
   c->n_ptiles = (int)t.size() / 2;
   A(&c->ptiles, t.size());
+  std::vector<int> t64;
+  const int Mt64 = (int)((M + 63) / 64);
+  for (int i = 0; i < Mt64; ++i) for (int j = i; j < Mt64; ++j) { t64.push_back(i); t64.push_back(j); }
+  c->n_tiles64 = (int)t64.size() / 2;
+  A(&c->tiles64, t64.size());
   if (rc != GP_OK) return rc;
   GP_HIP(c, hipMemcpyAsync(c->ptiles, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipMemcpyAsync(c->tiles64, t64.data(), t64.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   GP_HIP(c, hipStreamSynchronize(c->stream));
   // the pair kernel's split-n partials live in c->part: make sure it is large enough
-  const size_t need = (size_t)c->n_ptiles * 256 * 64;
+  const size_t need = std::max((size_t)c->n_ptiles * 256 * 64, (size_t)c->n_tiles64 * 4096 * 32);
   if (need > c->part_doubles) {
     (void)hipFree(c->part);
     c->part = nullptr;
@@ -591,7 +707,27 @@ static void launch_pairs(gp_ctx* c, int S) {
                      c->Mp, S, c->part, c->n_ptiles);
 }
 
+template <int QT>
+static void launch_pairs_mfma(gp_ctx* c, int S) {
+  hipLaunchKernelGGL((psi2_pairs_mfma_kernel<QT>), dim3(c->n_tiles64, S), dim3(256), 0, c->stream, (const double*)c->LET, (const double*)c->V2P,
+                     (const double*)c->ZP, (const int*)c->tiles64, (long)c->N, c->Mp, S, c->part, c->n_tiles64);
+}
+
 int run_phase1_b(gp_ctx* c) {
+  if (c->b_mfma) {
+    // 64 x 64 tiles x n-slices: several rounds of workgroups over the 512 resident slots, >= 256 points per slice
+    int S = (int)std::max<long>(1, std::min<long>(32, std::max<long>((2048 + c->n_tiles64 - 1) / c->n_tiles64, c->N / 4096)));
+    S = (int)std::min<long>(S, std::max<long>(1, c->N / 256));
+    switch (c->QB) {
+      case 32: launch_pairs_mfma<32>(c, S); break;
+      case 52: launch_pairs_mfma<52>(c, S); break;
+      default: launch_pairs_mfma<64>(c, S); break;
+    }
+    GP_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(psi2_reduce64_kernel, dim3(c->n_tiles64), dim3(256), 0, c->stream, c->part, c->tiles64, c->n_tiles64, S, c->M, c->Mp, c->stats);
+    GP_HIP(c, hipGetLastError());
+    return GP_OK;
+  }
   // n-slices: many more workgroups than resident slots (256 CUs x 7) so the last round is short, >= 1024 points per slice
   int S = (int)std::max<long>(1, std::min<long>(64, std::max<long>((4096 + c->n_ptiles - 1) / c->n_ptiles, c->N / 1024)));
   S = (int)std::min<long>(S, c->N);
@@ -621,8 +757,8 @@ static void launch_cols(gp_ctx* c, const PB2Args& a) {
 
 template <int QT>
 static int launch_cols_mfma(gp_ctx* c, const PB2Args& a) {
-  constexpr int LDZ = QT <= 32 ? 34 : 66;
-  const size_t smem = ((size_t)(2 * 64 + 4 * 16) * LDZ + c->Mp + 4 * (3 * QT + 1)) * sizeof(double);
+  constexpr int LDZ = QT + 2;
+  const size_t smem = ((size_t)(2 * 32 + 4 * 16) * LDZ + c->Mp + 4 * (3 * QT + 1)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_cols_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

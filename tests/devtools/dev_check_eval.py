@@ -1,7 +1,7 @@
 """Developer check (GPU box): full single-shard evaluation against the factorised CPU oracle."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from gparml_amd.engine import ShardEngine
 from oracle import factorised as Fz
 

@@ -1,7 +1,7 @@
 """Developer check (GPU box): potrf/inverse hook, phase 1 and global step against the CPU oracle."""
 import ctypes, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from gparml_amd import _lib
 from gparml_amd.engine import ShardEngine
 from oracle import factorised as Fz

@@ -1,7 +1,7 @@
 """Developer timing (GPU box): per-phase device times of one evaluation at a given size."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from gparml_amd.engine import ShardEngine
 from oracle import factorised as Fz
 N, D, M, Q = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (1000000, 100, 512, 10))]

@@ -1,7 +1,7 @@
 """Developer timing of phase 2 only (ablations via GP_P2_DBG)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from gparml_amd.engine import ShardEngine
 from oracle import factorised as Fz
 N, D, M, Q = 1000000, 100, 512, 10

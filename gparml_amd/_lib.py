@@ -24,6 +24,8 @@ SIGNATURES = {
     'gp_destroy': (ctypes.c_int, [_vp]),
     'gp_last_error': (ctypes.c_char_p, [_vp]),
     'gp_version': (ctypes.c_char_p, []),
+    'gp_csv_shape': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    'gp_csv_read': (ctypes.c_int, [ctypes.c_char_p, _dp, _i64, _i64, ctypes.c_int]),
     'gp_set_stream': (ctypes.c_int, [_vp, _vp]),
     'gp_upload_shard': (ctypes.c_int, [_vp, _dp, _dp, _dp, ctypes.c_int]),
     'gp_upload_embeddings': (ctypes.c_int, [_vp, _dp, _dp, ctypes.c_int]),

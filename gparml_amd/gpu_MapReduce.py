@@ -66,10 +66,17 @@ def _input_files(options):
 
 
 def _read_csv(path):
-    Y = numpy.genfromtxt(path, delimiter=',')                       # local_MapReduce.py:197
-    if Y.ndim == 1:
-        Y = numpy.atleast_2d(Y).T                                   # :198-199
-    return Y
+    """numpy.genfromtxt(path, delimiter=',') (local_MapReduce.py:197-199) through the library's parallel parser
+    (gp_csv_shape / gp_csv_read): a 1e6 x 100 shard takes seconds instead of ~300 s, and is parsed once per run."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    rows, cols = ctypes.c_int64(), ctypes.c_int64()
+    _lib.raise_for(lib.gp_csv_shape(path.encode(), ctypes.byref(rows), ctypes.byref(cols)), lib, None, 'gp_csv_shape')
+    Y = numpy.empty((rows.value, cols.value))
+    _lib.raise_for(lib.gp_csv_read(path.encode(), Y.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), rows.value, cols.value, 0),
+                   lib, None, 'gp_csv_read')
+    return Y                                                        # always 2-D: a one-column file is (N, 1) as after :198-199
 
 
 # ------------------------------------------------------------------------------------------------- init

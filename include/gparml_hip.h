@@ -142,6 +142,15 @@ int gp_cg_max_d(gp_ctx* ctx, double alpha, double* out);       /* max |alpha*d| 
  *        4 update_grad_new :231-243 | 5 set_grads */
 int gp_cg_update(gp_ctx* ctx, int which, double a);
 
+/* ---- shard ingest ------------------------------------------------------
+ * numpy.genfromtxt(file, delimiter=',') as statistics_mapper / embeddings_mapper call it on every evaluation
+ * (local_MapReduce.py:197-199, 325-327): comma-separated floating-point text -> row-major (rows, cols) doubles.
+ * Blank lines and '#' comment lines are skipped, empty or unparsable fields become NaN; a ragged file is GP_ERR_BAD_ARG
+ * (genfromtxt raises ValueError).  Host only, parsed in parallel (threads <= 0: all cores); the caller parses a shard once
+ * and keeps Y resident (gp_upload_shard). */
+int gp_csv_shape(const char* path, int64_t* rows, int64_t* cols);
+int gp_csv_read(const char* path, double* out, int64_t rows, int64_t cols, int threads);
+
 /* ---- test hooks (used by tests/ only) --------------------------------------------------------- */
 /* C = alpha*op(A)op(B) + beta*C through the library's FP64 MFMA GEMM core; A (m,k) or (k,m) if ta,
  * B (k,n) or (n,k) if tb; any sizes (padded internally) */

@@ -2,6 +2,7 @@
 // C = Psi1^T Y, KL), phase-2 gradient sums.  Reference: kernel_exp.py:13-148, partial_terms.py:38-87, 162-431,
 // local_MapReduce.py:183-248, 310-363.
 #include "gp_common.h"
+#include "fexp.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -98,13 +99,15 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 // arrives through wide scalar loads and feeds the FMAs as SGPR operands; no guards in the q loop (padding has u = 0).
 template <int QP>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
-                                                   long N, long Np, int M, int Q, long ld) {
-  // one wave = 128 columns (two adjacent per lane -> one 16-byte store per lane, 1 KB per wave-row) x 16 rows; the row's
-  // packed [mu | u | lnc1] record is wave-uniform and comes through scalar loads
+                                                   long N, long Np, int M, int Mp, int Q, long ld) {
+  // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
+  // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The row's packed
+  // [mu | u | lnc1] record is wave-uniform and comes through scalar loads.  The kernel is HBM-write bound.
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int col = blockIdx.x * 128 + 2 * lane;
-  const long row0 = blockIdx.y * 64L + wave * 16;
+  const int col = (blockIdx.x * 4 + wave) * 128 + 2 * lane;
+  if (col >= Mp) return;
+  const long row0 = blockIdx.y * 16L;
   const bool ok0 = col < M, ok1 = col + 1 < M;
   double z0[QP], z1[QP];
 #pragma unroll
@@ -125,8 +128,8 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       e1 = fma(row[QP + q] * d1, d1, e1);
     }
     double2 v;
-    v.x = (n < N && ok0) ? exp(row[2 * QP] - 0.5 * e0) : 0.0;
-    v.y = (n < N && ok1) ? exp(row[2 * QP] - 0.5 * e1) : 0.0;
+    v.x = (n < N && ok0) ? fexp(row[2 * QP] - 0.5 * e0) : 0.0;
+    v.y = (n < N && ok1) ? fexp(row[2 * QP] - 0.5 * e1) : 0.0;
     *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
   }
 }
@@ -266,8 +269,8 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 
 template <int QP>
 static void launch_psi1(gp_ctx* c) {
-  dim3 grid(c->Mp / 128, (unsigned)(c->Np / 64));
-  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Q, (long)c->LDK);
+  dim3 grid((c->Mp + 511) / 512, (unsigned)(c->Np / 16));
+  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q, (long)c->LDK);
 }
 
 int run_prep_and_generate(gp_ctx* c) {

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
 // Eight-wave variant of p1_kernel (the default; GP_P1_W8=0 selects the four-wave kernel): same 128x128 workgroup tile, same LDS
 // image and DMA traffic, but each 64x64 quadrant is shared by two waves (32 columns each): 32 accumulators per wave, 98 VGPRs,
 // four waves per SIMD to cover the barrier / LDS latency that two waves per SIMD leave exposed (measured 7.22 -> 6.90 ms).
-__global__ void __launch_bounds__(512, 2) p1_kernel8(P1Args p) {
+__global__ void __launch_bounds__(512, 4) p1_kernel8(P1Args p) {
   const int slice = p.bmap[2 * blockIdx.x], type = p.bmap[2 * blockIdx.x + 1];
   if (slice < 0) return;
   const int ti = p.tiles[2 * type], tj = p.tiles[2 * type + 1];

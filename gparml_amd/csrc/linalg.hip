@@ -10,6 +10,8 @@
 
 namespace gp {
 
+constexpr int kSplitK = 8;   // split-k factor of the M x M x M products of the global step (latency-bound: 16 tiles alone fill 6 % of the chip)
+
 constexpr int NB = 128;  // panel width = GEMM tile
 
 // ---------------------------------------------------------------------------------------------- diagonal panels
@@ -215,7 +217,7 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
   r.B = Linv; r.ldb = ld; r.sB = bs;   // B(k,j) = X[k][j] -> FREE_CONTIG
   r.C = Inv; r.ldc = ld; r.sC = bs;
   r.K = Mp; r.alpha = 1.0; r.beta = 0.0; r.tri = 0;
-  if (splitk_ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % 4 == 0) { r.splits = 4; r.ws = splitk_ws; }
+  if (splitk_ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0) { r.splits = kSplitK; r.ws = splitk_ws; }
   launch_gemm(st, FREE_CONTIG, FREE_CONTIG, Mp, Mp, batch, r);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -361,7 +363,7 @@ int run_global_step(gp_ctx* c) {
   GP_HIP(c, hipGetLastError());
   // factorise [Kmm ; A] in place, invert.  T1 is the 2 x 128 x Mp work panel.
   // split-k workspace: the phase-1 partial buffer is free during the global step (>= 600 tiles)
-  double* ws = ((size_t)2 * (Mp / TILE) * (Mp / TILE) * 4 * TILE * TILE <= c->part_doubles) ? c->part : nullptr;
+  double* ws = ((size_t)2 * (Mp / TILE) * std::max(Mp, Dp) / TILE * kSplitK * TILE * TILE <= c->part_doubles) ? c->part : nullptr;
   int rc = potrf_inverse_batched(c, st, Mp, 2, c->Kmm, c->Linv, c->Inv, c->T1, c->gs + GS_LOGDET_K, failf, ws);
   if (rc != GP_OK) return rc;
   double* Ki = c->Inv;
@@ -369,14 +371,14 @@ int run_global_step(gp_ctx* c) {
   // E = P C ; PsiE = Psi2 E ; T1 = E E^T ; T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki
   GemmP g;
   g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
-  const bool sk = ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % 4 == 0;
-  if (sk) { g.splits = 4; g.ws = ws; }
+  const bool sk = ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0;
+  if (sk) { g.splits = kSplitK; g.ws = ws; }
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.A = Psi2; g.lda = Mp; g.B = c->E; g.ldb = Dp; g.C = c->PsiE; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
-  { const int sps = g.splits; if ((Dp / KC) % 4 != 0 || Dp < 256) g.splits = 1; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
+  { const int sps = g.splits; if ((Dp / KC) % kSplitK != 0 || Dp < 256) g.splits = 1; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
   g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;

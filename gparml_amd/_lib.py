@@ -46,6 +46,7 @@ SIGNATURES = {
     'gp_cg_set_grads': (ctypes.c_int, [_vp]),
     'gp_cg_dots': (ctypes.c_int, [_vp, _dp]),
     'gp_cg_max_d': (ctypes.c_int, [_vp, ctypes.c_double, _dp]),
+    'gp_cg_abs': (ctypes.c_int, [_vp, _dp]),
     'gp_cg_update': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
     'gp_debug_gemm': (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_double, _dp, _dp, ctypes.c_double, _dp]),
     'gp_debug_potrf_inverse': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),

@@ -596,6 +596,37 @@ extern "C" int gp_cg_dots(gp_ctx* c, double* out6) {
   return cg_reduce(c, out6);
 }
 
+// out[0] += sum |g_new| ; out[1] = max |g_new|   (gd_local_MapReduce.py:38-61)
+__global__ void __launch_bounds__(256) cg_abs_kernel(long n2, const double* __restrict__ gnew, double* part) {
+  __shared__ double red[2][256];
+  double s = 0.0, m = 0.0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256L) { const double a = fabs(gnew[i]); s += a; m = fmax(m, a); }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = m;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] = fmax(red[1][threadIdx.x], red[1][threadIdx.x + w]); }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) part[blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+extern "C" int gp_cg_abs(gp_ctx* c, double* out2) {
+  if (!c || !out2) return GP_ERR_BAD_ARG;
+  GP_TRY(cg_ready(c, "gp_cg_abs"));
+  if (!c->have_dir) return fail(c, GP_ERR_STATE, "gp_cg_abs: no gradient vectors (gp_cg_set_grads first)");
+  GP_HIP(c, hipSetDevice(c->device));
+  const long n2 = 2L * c->N * c->Q;
+  const int nb = std::min(blocks_for(n2), 1024);
+  double* part = c->klpart + c->kl_blocks;   // spare tail (8192 doubles)
+  hipLaunchKernelGGL(cg_abs_kernel, dim3(nb), dim3(256), 0, c->stream, n2, c->g_new, part);
+  std::vector<double> h((size_t)nb * 2);
+  GP_HIP(c, hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  out2[0] = 0.0; out2[1] = 0.0;
+  for (int b = 0; b < nb; ++b) { out2[0] += h[(size_t)b * 2]; out2[1] = std::max(out2[1], h[(size_t)b * 2 + 1]); }
+  return GP_OK;
+}
+
 extern "C" int gp_cg_max_d(gp_ctx* c, double alpha, double* out) {
   if (!c || !out) return GP_ERR_BAD_ARG;
   GP_TRY(cg_ready(c, "gp_cg_max_d"));

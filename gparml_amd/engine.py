@@ -111,6 +111,12 @@ class ShardEngine(object):
         self._ck(self.lib.gp_cg_dots(self.h, out.ctypes.data_as(_lib._dp)), 'gp_cg_dots')
         return out
 
+    def cg_abs(self):
+        """local [sum |grad_now|, max |grad_now|] (gd_local_MapReduce.py:38-61)"""
+        out = np.zeros(2)
+        self._ck(self.lib.gp_cg_abs(self.h, out.ctypes.data_as(_lib._dp)), 'gp_cg_abs')
+        return out
+
     def cg_update(self, which, a=0.0):
         self._ck(self.lib.gp_cg_update(self.h, int(which), float(a)), 'gp_cg_update')
 

@@ -149,3 +149,44 @@ class ResidentCG(object):
 
     def embeddings_set_grads_update_grad_new(self, folder=None):
         self._upd(ShardEngine.CG_GRAD_NEW)
+
+
+class ResidentGD(object):
+    """The helper functions of gd_local_MapReduce.py:14-105 (the gradient-descent optimiser's vector algebra) on the
+    resident vectors; ``grad_now`` is the library's grad_new array.  ``folder`` is accepted and ignored."""
+
+    def __init__(self, model):
+        self.m = model
+
+    def _upd(self, which, a=0.0):
+        for e in self.m.engines:
+            e.cg_update(which, a)
+
+    def _abs(self):
+        s, mx = 0.0, 0.0
+        for e in self.m.engines:
+            a = e.cg_abs()
+            s += a[0]
+            mx = max(mx, a[1])
+        if self.m._dist is not None:
+            s = self.m._allreduce_scalar(s)
+            mx = self.m._allreduce_scalar(mx, 'max')
+        return s, mx
+
+    def embeddings_set_grads(self, folder=None):                       # :14-32  grad_now = latest, d = -latest
+        self._upd(ShardEngine.CG_SET_GRADS)
+
+    def embeddings_get_grads_current_grad(self, folder=None):          # :38-47  sum |grad_now|
+        return self._abs()[0]
+
+    def embeddings_get_grads_max_gradnow(self, folder=None):           # :49-61  max |grad_now|
+        return self._abs()[1]
+
+    def embeddings_set_grads_update_d(self, folder, gamma):            # :63-74  d = -(grad_now + gamma d)
+        self._upd(ShardEngine.CG_UPDATE_D, -gamma)
+
+    def embeddings_set_grads_update_X(self, folder, step_size):        # :76-94  X += step d
+        self._upd(ShardEngine.CG_UPDATE_X, step_size)
+
+    def embeddings_set_grads_update_grad_now(self, folder=None):       # :96-105 grad_now = latest
+        self._upd(ShardEngine.CG_GRAD_NEW)

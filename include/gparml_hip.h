@@ -138,6 +138,10 @@ int gp_cg_set_grads(gp_ctx* ctx);                              /* embeddings_set
  *         new.old (:128-140; the caller forms Gamma), max|d|] -- local sums, the host all-reduces them across shards */
 int gp_cg_dots(gp_ctx* ctx, double* out6);
 int gp_cg_max_d(gp_ctx* ctx, double alpha, double* out);       /* max |alpha*d| :142-155 */
+/* the gradient-descent optimiser's two reductions on grad_now (= grad_new here): out2 = [sum |grad_now|, max |grad_now|]
+ * (gd_local_MapReduce.py:38-61); its updates are gp_cg_update: set_grads -> 5, update_d(gamma) -> 1 with a = -gamma
+ * (d = -(grad_now + gamma d), :63-74), update_X -> 2 (:76-94), update_grad_now -> 4 (:96-105) */
+int gp_cg_abs(gp_ctx* ctx, double* out2);
 /* which: 0 reset_d :160-173 | 1 update_d(a=Gamma) :175-189 | 2 update_X(a=alpha) :191-214 | 3 update_grad_old :216-229 |
  *        4 update_grad_new :231-243 | 5 set_grads */
 int gp_cg_update(gp_ctx* ctx, int which, double a);

@@ -55,7 +55,7 @@ def load_reference():
     return mods
 
 
-def run(name, seed, shards, D, M, Q, fixed, iterations):
+def run(name, seed, shards, D, M, Q, fixed, iterations, optimiser='SCG_adapted', prefix='pipe'):
     mods = load_reference()
     pg, lmr = mods['parallel_GPLVM'], mods['local_MapReduce']
     work = tempfile.mkdtemp(prefix='gparml_gold_')
@@ -74,7 +74,7 @@ def run(name, seed, shards, D, M, Q, fixed, iterations):
         if fixed:
             np.save(os.path.join(dirs['embeddings'], 'shard_%d.embedding.npy' % i), X + 0.05 * rs.randn(n, Q))
     options = dict(input=dirs['input'], embeddings=dirs['embeddings'], statistics=dirs['statistics'], tmp=dirs['tmp'], parallel='local',
-                   iterations=iterations, keep=True, load=False, init='PCA', optimiser='SCG_adapted', drop_out_fraction=0,
+                   iterations=iterations, keep=True, load=False, init='PCA', optimiser=optimiser, drop_out_fraction=0,
                    local_no_pool=False, M=M, Q=Q, D=D, fixed_embeddings=fixed, fixed_beta=False)
     rec = {'n_shards': np.int64(len(shards)), 'D': np.int64(D), 'M': np.int64(M), 'Q': np.int64(Q), 'fixed': np.int64(fixed)}
     for i, Y in enumerate(Ys):
@@ -116,7 +116,7 @@ def run(name, seed, shards, D, M, Q, fixed, iterations):
         pg.main(options)
     rec['n_calls'] = np.int64(len(calls))
     rec['N'] = np.int64(sum(shards))
-    path = os.path.join(HERE, 'pipe_%s.npz' % name)
+    path = os.path.join(HERE, '%s_%s.npz' % (prefix, name))
     np.savez_compressed(path, **rec)
     shutil.rmtree(work)
     print('%-12s %d calls, f: %s -> %s (%d bytes)' % (name, len(calls), rec['call0_f'], rec['call%d_f' % (len(calls) - 1)], os.path.getsize(path)))
@@ -128,3 +128,5 @@ if __name__ == '__main__':
     run('gplvm_2shards', 21, (30, 26), 3, 4, 2, False, 2)
     run('sparsegp_2shards', 22, (40, 33), 4, 6, 3, True, 2)
     run('config1_1shard', 23, (120,), 4, 2, 2, False, 2)
+    # the gradient-descent optimiser (parallel_GPLVM.py:104-105, gd.py): accepted and rejected steps, free embeddings
+    run('gplvm_2shards', 24, (28, 31), 3, 4, 2, False, 9, optimiser='GD', prefix='gdpipe')

@@ -37,27 +37,56 @@ __global__ void __launch_bounds__(256) b_tables_kernel(const double* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ mu, const double* __restrict__ Wn, const double* __restrict__ Vn,
-                                                    const double* __restrict__ lnc2h, const double* __restrict__ Z, long N, long Np,
-                                                    int M, int Mp, int Q, double* __restrict__ LE, double* __restrict__ LEA) {
-  // both tables are n-major [Np][Mp]; padded entries hold kPadLog (their exp is exactly 0)
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const long n = blockIdx.y * 16L + ty;
-  const int m = blockIdx.x * 16 + tx;
-  double e = kPadLog, ea = kPadLog;
-  if (n < N && m < M) {
-    e = 0.0;
-    for (int q = 0; q < Q; ++q) {
-      const double d = mu[n * Q + q] - Z[(long)m * Q + q];
-      e = fma(Wn[n * Q + q] * d, d, e);
+// LE and LEA (n-major [Np][Mp], padded entries = kPadLog so that their exp is exactly 0).  Same shape as psi1_kernel: a wave
+// owns 64*CPL columns (z_m in registers), the point's padded rows [mu | w | -2V] are wave-uniform scalar loads, a workgroup
+// writes whole rows (HBM-write bound: 16 B per (n, m)).
+//   LE  = 1/2 ln c2_n - 1/2 sum_q w_nq (mu_nq - z_mq)^2
+//   LEA = LE + sum_q V_nq z_mq^2: with it the pair exponent is LEA_nm + LEA_nm' - 2 sum_q V_nq z_mq z_m'q
+template <int QT, int CPL>
+__global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ MUP, const double* __restrict__ WP, const double* __restrict__ V2P,
+                                                    const double* __restrict__ lnc2h, const double* __restrict__ ZP, long N, int M, int Mp,
+                                                    double* __restrict__ LE, double* __restrict__ LEA) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = (blockIdx.x * 4 + wave) * (64 * CPL) + CPL * lane;
+  if (col >= Mp) return;
+  double z[CPL][QT];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+#pragma unroll
+    for (int q = 0; q < QT; ++q) z[c][q] = ZP[(long)(col + c) * QT + q];
+  const long row0 = blockIdx.y * 16L;
+#pragma unroll 2
+  for (int r = 0; r < 16; ++r) {
+    const long n = row0 + r;                    // < Np (a multiple of 128)
+    const double* mu = MUP + n * QT;            // wave-uniform
+    const double* w = WP + n * QT;
+    const double* v2 = V2P + n * QT;
+    const double l0 = lnc2h[n];
+    double e[CPL], ea[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      double s = 0.0, t = 0.0;
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        const double d = mu[q] - z[c][q];
+        s = fma(w[q] * d, d, s);
+        t = fma(v2[q] * z[c][q], z[c][q], t);
+      }
+      const bool live = n < N && col + c < M;
+      e[c] = live ? l0 - 0.5 * s : kPadLog;
+      ea[c] = live ? e[c] - 0.5 * t : kPadLog;   // V = -V2P / 2
     }
-    e = lnc2h[n] - 0.5 * e;
-    // LEA = LE + sum_q V_nq z_mq^2: with it the pair exponent is LEA_nm + LEA_nm' - 2 sum_q V_nq z_mq z_m'q
-    ea = e;
-    for (int q = 0; q < Q; ++q) { const double z = Z[(long)m * Q + q]; ea = fma(Vn[n * Q + q] * z, z, ea); }
+    if (CPL == 2) {
+      double2 a, b2;
+      a.x = e[0]; a.y = e[CPL - 1]; b2.x = ea[0]; b2.y = ea[CPL - 1];
+      *reinterpret_cast<double2*>(&LE[n * Mp + col]) = a;
+      *reinterpret_cast<double2*>(&LEA[n * Mp + col]) = b2;
+    } else {
+      LE[n * Mp + col] = e[0];
+      LEA[n * Mp + col] = ea[0];
+    }
   }
-  LE[n * Mp + m] = e;
-  LEA[n * Mp + m] = ea;
 }
 
 __global__ void __launch_bounds__(256) dz2_kernel(const double* __restrict__ Z, int M, int Q, double* __restrict__ DZ2) {
@@ -660,6 +689,13 @@ int run_dz2(gp_ctx* c) {
   return GP_OK;
 }
 
+template <int QT, int CPL>
+static void launch_le(gp_ctx* c) {
+  dim3 grid((c->Mp + 256 * CPL - 1) / (256 * CPL), (unsigned)(c->Np / 16));
+  hipLaunchKernelGGL((b_le_kernel<QT, CPL>), grid, dim3(256), 0, c->stream, (const double*)c->MUP, (const double*)c->WP, (const double*)c->V2P,
+                     (const double*)c->lnc2h, (const double*)c->ZP, (long)c->N, c->M, c->Mp, c->LE, c->LET);
+}
+
 int run_generate_b(gp_ctx* c) {
   int rc = ensure_regime_b_buffers(c);
   if (rc != GP_OK) return rc;
@@ -670,9 +706,15 @@ int run_generate_b(gp_ctx* c) {
   GP_HIP(c, hipMemcpyAsync(c->alphaP, c->alpha, (size_t)c->Q * 8, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(zpad_kernel, dim3((unsigned)(((long)c->Mp * c->QB + 255) / 256)), dim3(256), 0, c->stream, c->Z, c->M, c->Mp, c->Q, c->QB,
                      c->ZP, c->Z1P);
-  dim3 grid(c->Mp / 16, (unsigned)(c->Np / 16));
-  hipLaunchKernelGGL(b_le_kernel, grid, dim3(256), 0, c->stream, c->mu, c->Wn, c->Vn, c->lnc2h, c->Z, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                     c->LE, c->LET);
+  switch (c->QB) {
+    case 4: launch_le<4, 2>(c); break;
+    case 10: launch_le<10, 2>(c); break;
+    case 16: launch_le<16, 2>(c); break;
+    case 24: launch_le<24, 2>(c); break;
+    case 32: launch_le<32, 1>(c); break;
+    case 52: launch_le<52, 1>(c); break;
+    default: launch_le<64, 1>(c); break;
+  }
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }

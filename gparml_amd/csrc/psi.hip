@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) pack_pu_kernel(const double* __restrict__
 // p1_reduce_kernel.  All tile types of one slice sit on one XCD (block b runs on XCD b % 8) so the slice's rows
 // are fetched from HBM once and re-read from that XCD's L2.
 struct P1Args {
-  const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; int psi2_tiles; int dbg; const int* bmap;
+  const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; const int* bmap;
 };
 
 __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
@@ -185,9 +185,7 @@ __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow0 = (wave >> 1) * WT, wcol0 = (wave & 1) * WT;
-  const bool skip = (ti == tj) && (wave == 2) && !(p.dbg & 4);  // mirror image of wave 1 on a diagonal tile
-  if (p.dbg & 8) { if (((blockIdx.x >> 3) & 32) != 0) __builtin_amdgcn_s_setprio(2); }
-  if (p.dbg & 16) { if (((blockIdx.x >> 3) & 1) != 0) __builtin_amdgcn_s_setprio(2); }
+  const bool skip = (ti == tj) && (wave == 2);  // mirror image of wave 1 on a diagonal tile
   const int c0 = slice * p.cps, c1 = min(p.total_chunks, c0 + p.cps);
   const double* Ab = p.Kaug + (long)ti * TILE + (long)c0 * KC * p.ld;
   const double* Bb = p.Kaug + (long)tj * TILE + (long)c0 * KC * p.ld;
@@ -202,11 +200,11 @@ __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nc && !(p.dbg & 1)) {
+    if (c + 1 < nc) {
       tile_dma<FREE_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * step, p.ld, wave, lane);
       tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * step, p.ld, wave, lane);
     }
-    if (!skip && !(p.dbg & 2)) mma_chunk<FREE_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+    if (!skip) mma_chunk<FREE_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
     dma_wait();
     __syncthreads();
   }
@@ -393,8 +391,7 @@ int run_phase1(gp_ctx* c) {
   int S = std::max(1, std::min(8 * L + n_shared, p.total_chunks));
   p.cps = (p.total_chunks + S - 1) / S;
   S = (p.total_chunks + p.cps - 1) / p.cps;
-  p.S = S; p.part = c->part; p.psi2_tiles = 0;
-  { const char* e = getenv("GP_P1_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.S = S; p.part = c->part;
   if (c->bmap_T != T || c->bmap_S != S) {
     const int per_xcd = (T <= 64) ? 64 : (S * T + 7) / 8;
     std::vector<int> slot(8 * per_xcd * 2, -1);     // [xcd][j] -> (slice, type)
@@ -448,7 +445,7 @@ int run_phase1(gp_ctx* c) {
 struct P2Args {
   const double* Kaug; long ld; const double* Bm; const double* Xa; const double* Zaug;
   double* Rpart; double* HZp;
-  int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend; long Np; int dbg;
+  int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend; long Np;
 };
 
 constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
@@ -471,11 +468,6 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
   const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
   const int ngx = (p.CXp / 4 + GRP - 1) / GRP, ngz = (p.CZp / 4 + GRP - 1) / GRP;
   double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
-  if (p.dbg & 12) {
-    // experiment: stagger the two workgroups of a CU by half a tile so that their epilogues do not coincide
-    const bool late = (p.dbg & 4) ? (((blockIdx.x >> 3) & 32) != 0) : (((blockIdx.x >> 3) & 1) != 0);
-    if (late) { const long t_end = wall_clock64() + 6000; while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32); }
-  }
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;                  // rows n, k contiguous
@@ -492,12 +484,11 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
         tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
         tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
       }
-      if (!(p.dbg & 2)) mma_chunk<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
+      mma_chunk<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
       dma_wait();
       __syncthreads();
     }
     mfma_drain(acc.v[3][15]);
-    if (p.dbg & 1) { __syncthreads(); continue; }
     // W = G o Psi1 (same element positions as the accumulators)
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) {
@@ -764,10 +755,9 @@ int run_phase2(gp_ctx* c) {
   p.S = S;
   p.kbeg = c->regime_A ? 0 : c->Mp / KC;
   p.kend = (c->Mp + (int)round_up(c->D, KC)) / KC;   // chunks beyond the last real Y column are all zero
-  { const char* e = getenv("GP_P2_DBG"); p.dbg = e ? atoi(e) : 0; }
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
   (void)hipEventRecord(c->ev[12], c->stream);
-  const bool fast = !ppath && c->CXp <= 24 && !(p.dbg & 16);
+  const bool fast = !ppath && c->CXp <= 24;
   if (ppath) hipLaunchKernelGGL((p2_kernel<true>), dim3(blocks), dim3(256), 0, c->stream, p);
   else if (!fast) hipLaunchKernelGGL((p2_kernel<false>), dim3(blocks), dim3(256), 0, c->stream, p);
   else {

@@ -26,19 +26,20 @@ class _SplitVectors(object):
         self.ops, self.folder, self.local = ops, folder, local
 
     def _plus(self, host_value, getter, *args):
-        return host_value + getter(self.folder, *args) if self.local else host_value
+        # ``ops`` may be None when there is no shard part (fixed embeddings): look the getter up only when it is used
+        return host_value + getattr(self.ops, getter)(self.folder, *args) if self.local else host_value
 
     def slope(self, d, g):                       # mu = d . grad_new
-        return self._plus(np.dot(d, g), self.ops.embeddings_get_grads_mu)
+        return self._plus(np.dot(d, g), 'embeddings_get_grads_mu')
 
     def length2(self, d):                        # kappa = d . d
-        return self._plus(np.dot(d, d), self.ops.embeddings_get_grads_kappa)
+        return self._plus(np.dot(d, d), 'embeddings_get_grads_kappa')
 
     def curvature(self, d, g_probe, g):          # theta numerator = d . (grad(x + sigma d) - grad_new)
-        return self._plus(np.dot(d, g_probe - g), self.ops.embeddings_get_grads_theta)
+        return self._plus(np.dot(d, g_probe - g), 'embeddings_get_grads_theta')
 
     def norm2(self, g):                          # grad_new . grad_new
-        return self._plus(np.dot(g, g), self.ops.embeddings_get_grads_current_grad)
+        return self._plus(np.dot(g, g), 'embeddings_get_grads_current_grad')
 
     def largest_move(self, alpha, d):            # max |alpha d|
         host = np.max(np.abs(alpha * d))

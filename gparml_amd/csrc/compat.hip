@@ -140,6 +140,7 @@ int compat_build(gp_ctx* c, int which, double** out, long* count) {
   double* p2 = nullptr;
   if (needs_p2) {
     if (which == GP_ARR_PSI2_POINTS) p2 = buf; else GP_HIP(c, hipMalloc((void**)&p2, N * M * M * 8));
+    if (!c->regime_A) { const int rc = run_dz2(c); if (rc != GP_OK) return rc; }
     hipLaunchKernelGGL(psi2_points_kernel, dim3(grid_for(N * M * M)), dim3(256), 0, c->stream, c->Kaug, (long)c->LDK, c->LE, c->Mp, c->Vn, c->DZ2,
                        N, (int)M, (int)Q, c->regime_A ? 1 : 0, p2);
   }

@@ -649,7 +649,7 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   A(&c->LE, (size_t)Np * Mp); A(&c->LET, (size_t)Np * Mp); A(&c->Vn, (size_t)Np * Q); A(&c->Wn, (size_t)Np * Q);
   A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB); A(&c->Z1P, (size_t)Mp * c->QB); A(&c->WP, (size_t)Np * c->QB); A(&c->MUP, (size_t)Np * c->QB);
   A(&c->alphaP, (size_t)c->QB);
-  A(&c->DZ2, (size_t)M * M * Q); A(&c->lnc2h, (size_t)Np);
+  A(&c->lnc2h, (size_t)Np);
   // phase-2 pair kernel: grid (point chunks, groups of <= 4 64-column slabs); >= 16 points per workgroup, <= 4096 chunks
   c->nslab = (int)((M + 63) / 64);
   c->ppb = (int)std::max<long>(16, (c->N + 4095) / 4096);
@@ -682,8 +682,10 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   return GP_OK;
 }
 
+// (z_mq - z_m'q)^2 for the compat path's per-point psi2 tensor only (the pair kernels use the padded Z tables)
 int run_dz2(gp_ctx* c) {
   const long total = (long)c->M * c->M * c->Q;
+  if (!c->DZ2) GP_HIP(c, hipMalloc((void**)&c->DZ2, std::max<long>(total, 1) * sizeof(double)));
   hipLaunchKernelGGL(dz2_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, c->stream, c->Z, c->M, c->Q, c->DZ2);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -698,8 +700,6 @@ static void launch_le(gp_ctx* c) {
 
 int run_generate_b(gp_ctx* c) {
   int rc = ensure_regime_b_buffers(c);
-  if (rc != GP_OK) return rc;
-  rc = run_dz2(c);
   if (rc != GP_OK) return rc;
   hipLaunchKernelGGL(b_tables_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, c->mu, c->S, c->alpha, (long)c->N, (long)c->Np, c->Q,
                      c->sf2, c->Vn, c->Wn, c->lnc2h, c->V2P, c->QB, c->WP, c->MUP);

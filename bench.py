@@ -24,14 +24,14 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 (vector = matrix); ubench ceiling 74 (profiles/r01_ubench_f64_mfma4x4x4.txt)
 
 
-def synthetic(N, D, M, Q, seed):
+def synthetic(N, D, M, Q, seed, regime='A'):
     """SURVEY.md 8(d) synthetic shard; generated with numpy on the host, outside the timed region."""
     rs = np.random.RandomState(seed)
     X = rs.randn(N, Q)
     W = np.random.RandomState(1234).randn(Q, D)          # same map on every rank
     Y = np.sin(X.dot(W)) + 0.1 * rs.randn(N, D)
     X_mu = X + 0.05 * rs.randn(N, Q)
-    X_S = np.zeros((N, Q))
+    X_S = np.zeros((N, Q)) if regime == 'A' else rs.uniform(0.05, 0.55, size=(N, Q))   # SURVEY.md 8(d)
     rz = np.random.RandomState(1)
     Z = np.random.RandomState(0).randn(4 * M, Q)[rz.permutation(4 * M)[:M]] + 0.05 * rz.randn(M, Q)   # same Z on every rank
     return dict(Y=Y, X_mu=X_mu, X_S=X_S, Z=Z, sf2=1.0, alpha=np.full(Q, 0.1), beta=10.0)
@@ -65,6 +65,8 @@ def main():
     ap.add_argument('--D', type=int, default=100)
     ap.add_argument('--M', type=int, default=512)
     ap.add_argument('--Q', type=int, default=10)
+    ap.add_argument('--regime', choices=['A', 'B'], default='A',
+                    help='A (default, the metric\'s configuration): X_S = 0, fixed embeddings; B: Bayesian GPLVM, X_S > 0, embedding gradients')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rows', type=int, default=200000)
     a = ap.parse_args()
@@ -88,7 +90,8 @@ def main():
     from gparml_amd.engine import ShardEngine
     from gparml_amd.dist import DistributedEvaluator
 
-    d = synthetic(a.N, a.D, a.M, a.Q, seed=100 + rank)
+    d = synthetic(a.N, a.D, a.M, a.Q, seed=100 + rank, regime=a.regime)
+    emb = a.regime == 'B'
     eng = ShardEngine(a.N, a.D, a.M, a.Q, device=local_rank)
     eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
     eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=a.N * world)
@@ -101,12 +104,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        out = ev.evaluate(False)
+        out = ev.evaluate(emb)
     barrier()
     t0 = time.time()
     kern = {'psi1_ms': 0.0, 'p1_kernel_ms': 0.0, 'p2_kernel_ms': 0.0, 'global_ms': 0.0, 'total_ms': 0.0}
     for _ in range(a.steps):
-        out = ev.evaluate(False)
+        out = ev.evaluate(emb)
         tm = eng.timings()            # HIP events on the engine's stream around each kernel of this evaluation
         for k in kern:
             kern[k] += tm[k]
@@ -146,7 +149,19 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'gp::p2_fast_kernel<6>', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / FP64_PEAK_TFLOPS, 'traffic': traffic},
         }
-        if not a.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
+        if a.regime == 'B':
+            # not the metric's configuration: the free-embedding (Bayesian GPLVM) variant of the same size.  The pair kernels
+            # run on the FP64 pipe that VALU and MFMA share, so the whole evaluation is priced against the same peak with
+            # SURVEY.md 8(d)'s regime-B figure W_B = N M^2 (4Q + 10)
+            W_B = float(N) * M * M * (4.0 * Q + 10.0)
+            achB = W_B / (kern['total_ms'] * 1e-3) / 1e12
+            res['config']['workload'] = 'N=%d, D=%d, M=%d, Q=%d, ARD-RBF Bayesian GPLVM (free embeddings, X_S > 0), %d shard(s)' % (N, D, M, Q, world)
+            res['config']['regime'] = 'B'
+            res['config']['eval_flops_survey_8d'] = W_B
+            res['config']['eval_fraction_of_fp64_peak'] = achB / FP64_PEAK_TFLOPS
+            res['roofline'] = {'bound': 'mfma', 'kernel': 'whole evaluation (psi2 pair kernels, FP64 VALU/MFMA pipe)', 'achieved': achB,
+                               'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achB / FP64_PEAK_TFLOPS, 'traffic': None}
+        if not a.no_cpu_baseline and world == 1 and a.regime == 'A':     # rank 0 at N=1 only
             res['cpu_baseline'] = cpu_baseline(D, M, Q, N, min(a.cpu_rows, N))
         print(json.dumps(res))
     if world > 1:

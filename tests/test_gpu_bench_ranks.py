@@ -78,3 +78,50 @@ def test_two_rank_evaluation_matches_the_oracle(tmp_path):
            '--master-port', str(port), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0 and r.stdout.count('RANK_OK') == 2, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+SCG_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from gparml_amd.resident import ResidentCG, ResidentGD, ResidentModel
+from gparml_amd.scg_adapted import SCG_adapted
+from gparml_amd.gd import GD
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+for fname, optimiser, iters in (('pipe_gplvm_2shards.npz', 'scg', 2), ('gdpipe_gplvm_2shards.npz', 'gd', 9)):
+    z = np.load(os.path.join(%(root)r, 'tests', 'golden', fname)); g = {k: z[k] for k in z.files}
+    M, Q, D, N = int(g['M']), int(g['Q']), int(g['D']), int(g['N'])
+    mine = [(g['Y_%%d' %% rank], g['call0_in_shard%%d_embedding' %% rank], g['call0_in_shard%%d_variance' %% rank])]   # one shard per rank
+    model = ResidentModel(mine, M, Q, D, fixed_embeddings=False)
+    assert model.N == N, (model.N, N)                     # all-reduced point count
+    calls = []
+    def f_and_g(x, it, step=0):
+        f, grad = model.likelihood_and_gradient(x, it, step); calls.append((np.array(x), f, grad)); return f, grad
+    if optimiser == 'scg':
+        x_opt = SCG_adapted(f_and_g, g['call0_x'].copy(), ResidentCG(model), fixed_embeddings=False, maxiters=iters, xtol=0, ftol=0, gtol=0)[0]
+    else:
+        x_opt = GD(f_and_g, g['call0_x'].copy(), ResidentGD(model), fixed_embeddings=False, maxiters=iters)[0]
+    f_and_g(x_opt, 'f')
+    assert len(calls) == int(g['n_calls']), (optimiser, len(calls), int(g['n_calls']))
+    for k, (x, f, grad) in enumerate(calls):
+        assert np.max(np.abs(x - g['call%%d_x' %% k])) <= 1e-7 * np.max(np.abs(g['call%%d_x' %% k])) + 1e-12, (optimiser, k, 'x')
+        assert abs(f - float(g['call%%d_f' %% k])) <= 1e-6 * abs(float(g['call%%d_f' %% k])), (optimiser, k, 'f')
+        assert np.max(np.abs(grad - g['call%%d_g' %% k])) <= 2e-5 * np.max(np.abs(g['call%%d_g' %% k])), (optimiser, k, 'g')
+    model.close()
+dist.destroy_process_group()
+print('RANK_OK', rank)
+"""
+
+
+def test_two_rank_resident_optimisation_reproduces_the_reference_runs(tmp_path):
+    """One shard per process (two processes on device 0, gloo): the reference's 2-shard SCG and GD runs are reproduced call
+    by call -- statistics / gradient all-reduces on the device buffers plus the optimisers' scalar sum / max reductions."""
+    script = tmp_path / 'scg_rank_script.py'
+    script.write_text(SCG_RANK_SCRIPT % {'root': ROOT})
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and r.stdout.count('RANK_OK') == 2, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,0 +1,48 @@
+"""Developer fuzz (GPU box): extreme hyper-parameters (sf2, beta, alpha over many decades) in both regimes against the oracle."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import numpy as np
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+bad = 0
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
+    regime = 'AB'[rs.randint(2)]
+    Q = int(rs.choice([2, 5, 10, 30])); M = int(rs.choice([8, 40, 130])); N = int(rs.choice([50, 400])); D = int(rs.choice([2, 12]))
+    d = Fz.synthetic_shard(max(N, M), D, M, Q, regime=regime, seed=10 + it, zseed=20 + it, alpha_value=1.0)
+    for k in ('Y', 'X_mu', 'X_S'):
+        d[k] = d[k][:N]
+    d['sf2'] = float(10.0 ** rs.uniform(-3, 3)); d['beta'] = float(10.0 ** rs.uniform(-2, 4))
+    d['alpha'] = 10.0 ** rs.uniform(-2, 1.5, size=Q)
+    try:
+        ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+        ok_ref = np.isfinite(ref['F'])
+    except Exception as e:
+        ok_ref = False
+    dz = d['Z'][:, None, :] - d['Z'][None, :, :]
+    Kmm = d['sf2'] * np.exp(-0.5 * np.sum(d['alpha'] * dz * dz, axis=2))
+    eng = ShardEngine(N, D, M, Q)
+    try:
+        eng.upload_shard(d['Y'], d['X_mu'], d['X_S']); eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        eng.phase1(); eng.global_step(); eng.phase2(True); out = eng.finish()
+        if not ok_ref:
+            print('ref failed, gpu F=%.3e' % out['F'])
+        else:
+            cond = max(np.linalg.cond(Kmm), np.linalg.cond(Kmm + d['beta'] * ref['stats']['sum_exp_K_mi_K_im']))   # both are inverted
+            eF = rel(out['F'], ref['F']); eg = max(rel(out[k], ref[k]) for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'))
+            egx = rel(eng.download('GRAD_X_MU'), ref['grad_X_mu'])
+            flag = (eF > 1e-6 or eg > 1e-5 or egx > 1e-5) and cond < 1e8
+            bad += flag
+            if flag:
+                print('   ', {k: '%.1e (|ref| %.1e)' % (rel(out[k], ref[k]), float(np.max(np.abs(ref[k])))) for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta')})
+            print('%s %s N=%d M=%d Q=%d sf2=%.1e beta=%.1e cond=%.1e F=%.1e g=%.1e gx=%.1e' % ('BAD' if flag else ('ill' if cond >= 1e8 else 'ok '), regime, N, M, Q, d['sf2'], d['beta'], cond, eF, eg, egx))
+    except Exception as e:
+        print('GPU exception (%s): %s | ref ok=%s' % (type(e).__name__, str(e)[:100], ok_ref))
+        bad += bool(ok_ref) and np.linalg.cond(Kmm) < 1e8
+    eng.close()
+print('cases over tolerance at cond < 1e8: %d' % bad)

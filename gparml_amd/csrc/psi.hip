@@ -97,17 +97,17 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 // block: 64 rows x 128 columns; thread: one column, 32 rows; z_m lives in registers (QP = Q rounded up to 2, zero
 // padded); the row index is wave-uniform (readfirstlane), so the packed per-point row PU[n] = [mu_n | u_n | ln c1_n]
 // arrives through wide scalar loads and feeds the FMAs as SGPR operands; no guards in the q loop (padding has u = 0).
+constexpr int PSI1_ROWS = 128;   // rows per workgroup of psi1_kernel (Np is a multiple of 128)
 template <int QP>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                    long N, long Np, int M, int Mp, int Q, long ld) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
-  // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The row's packed
-  // [mu | u | lnc1] record is wave-uniform and comes through scalar loads.  The kernel is HBM-write bound.
+  // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
+  // [mu | u | lnc1] records are staged in LDS (below).
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = (blockIdx.x * 4 + wave) * 128 + 2 * lane;
-  if (col >= Mp) return;
-  const long row0 = blockIdx.y * 16L;
+  const long row0 = blockIdx.y * (long)PSI1_ROWS;
   const bool ok0 = col < M, ok1 = col + 1 < M;
   double z0[QP], z1[QP];
 #pragma unroll
@@ -116,21 +116,42 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
     z1[q] = (q < Q && ok1) ? Z[(long)(col + 1) * Q + q] : 0.0;
   }
   constexpr int W = 2 * QP + 2;   // row width of PU (doubles), a multiple of 2
-#pragma unroll 2
-  for (int r = 0; r < 16; ++r) {
-    const long n = row0 + r;       // Np is a multiple of 64: always in range
-    const double* row = PU + n * W;
-    double e0 = 0.0, e1 = 0.0;
+  // Records of 16 rows at a time: one coalesced load into LDS, read back as broadcast operands; the next group's records
+  // travel while the current group is computed.  (Per-row scalar loads cost a serial memory round trip per row and held the
+  // kernel at 1.9 ms although plain stores reach 5.5 TB/s: tools/ubench/store_ubench.hip.)
+  constexpr int GR = 16, NG = PSI1_ROWS / GR, RPT = (GR * W + 255) / 256;
+  __shared__ double rec_s[2][GR * W];
+  double stage[RPT];
 #pragma unroll
-    for (int q = 0; q < QP; ++q) {
-      const double d0 = row[q] - z0[q], d1 = row[q] - z1[q];
-      e0 = fma(row[QP + q] * d0, d0, e0);
-      e1 = fma(row[QP + q] * d1, d1, e1);
+  for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * W) rec_s[0][e] = PU[row0 * W + e]; }
+  __syncthreads();
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; stage[i] = e < GR * W ? PU[(row0 + GR * (g + 1)) * W + e] : 0.0; }
     }
-    double2 v;
-    v.x = (n < N && ok0) ? fexp(row[2 * QP] - 0.5 * e0) : 0.0;
-    v.y = (n < N && ok1) ? fexp(row[2 * QP] - 0.5 * e1) : 0.0;
-    *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
+    const double* recs = rec_s[g & 1];
+#pragma unroll 1
+    for (int r = 0; r < GR; ++r) {
+      const long n = row0 + GR * g + r;       // Np is a multiple of 128: always in range
+      const double* row = recs + r * W;
+      double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const double d0 = row[q] - z0[q], d1 = row[q] - z1[q];
+        e0 = fma(row[QP + q] * d0, d0, e0);
+        e1 = fma(row[QP + q] * d1, d1, e1);
+      }
+      double2 v;
+      v.x = (n < N && ok0) ? fexp(row[2 * QP] - 0.5 * e0) : 0.0;
+      v.y = (n < N && ok1) ? fexp(row[2 * QP] - 0.5 * e1) : 0.0;
+      if (col < Mp) *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
+    }
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * W) rec_s[(g + 1) & 1][e] = stage[i]; }
+    }
+    __syncthreads();
   }
 }
 
@@ -334,7 +355,7 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 
 template <int QP>
 static void launch_psi1(gp_ctx* c) {
-  dim3 grid((c->Mp + 511) / 512, (unsigned)(c->Np / 16));
+  dim3 grid((c->Mp + 511) / 512, (unsigned)(c->Np / PSI1_ROWS));
   hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q, (long)c->LDK);
 }
 

@@ -27,6 +27,7 @@ __global__ void __launch_bounds__(256) copy_y_kernel(const double* __restrict__ 
 struct PrepArgs {
   const double* Xmu; const double* Xs; const double* dir; const double* alpha;
   double* mu; double* S; double* U; double* lnc1; double* Xa; double* klpart;
+  double* PU; int QP;   // packed per-point records [mu (QP) | u (QP) | ln c1 | 0] for psi1_kernel (PU == nullptr: not used); padding stays zero from the allocation
   long N, Np; int Q, CXp; double step, sf2; int raw, regimeA, fixedA;
 };
 
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(256) prep_elem_kernel(PrepArgs a) {
     const double al = a.alpha[q];
     const double u = al / (al * s + 1.0);
     a.U[i] = u;
+    if (a.PU) { double* rec = a.PU + n * (2 * a.QP + 2); rec[q] = m; rec[a.QP + q] = u; }
     double f1, f2;
     if (a.fixedA) { f1 = m; f2 = m * m; } else { f1 = u * m; f2 = u; }
     if (n >= a.N) { f1 = 0.0; f2 = 0.0; }
@@ -80,6 +82,7 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
       kl += 0.5 * klrow;
     }
     a.lnc1[n] = lnc;
+    if (a.PU) a.PU[n * (2 * a.QP + 2) + 2 * a.QP] = lnc;
     a.Xa[n * a.CXp + 2 * a.Q] = (n < a.N) ? 1.0 : 0.0;
     for (int c = 2 * a.Q + 1; c < a.CXp; ++c) a.Xa[n * a.CXp + c] = 0.0;
   }
@@ -94,9 +97,8 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 
 // ------------------------------------------------------------------------------------------------ Psi1
 // Kaug[n][m] = exp(ln c1_n - 1/2 sum_q u_nq (mu_nq - z_mq)^2), u = alpha/(alpha S + 1)   (kernel_exp.py:80)
-// block: 64 rows x 128 columns; thread: one column, 32 rows; z_m lives in registers (QP = Q rounded up to 2, zero
-// padded); the row index is wave-uniform (readfirstlane), so the packed per-point row PU[n] = [mu_n | u_n | ln c1_n]
-// arrives through wide scalar loads and feeds the FMAs as SGPR operands; no guards in the q loop (padding has u = 0).
+// z_m lives in registers (QP = Q rounded up to 2, zero padded); the packed per-point records PU[n] = [mu_n | u_n | ln c1_n]
+// (written by the prep kernels) are staged through LDS; no guards in the q loop (padding has u = 0).
 constexpr int PSI1_ROWS = 128;   // rows per workgroup of psi1_kernel (Np is a multiple of 128)
 template <int QP>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
@@ -171,22 +173,6 @@ __global__ void __launch_bounds__(256) psi1_generic_kernel(const double* __restr
       e = fma(U[n * Q + q] * d, d, e);
     }
     Kaug[n * ld + col] = (n < N && colok) ? exp(lnc1[n] - 0.5 * e) : 0.0;
-  }
-}
-
-// PU[n] = [mu_n (QP) | u_n (QP) | ln c1_n | 0]
-__global__ void __launch_bounds__(256) pack_pu_kernel(const double* __restrict__ mu, const double* __restrict__ U, const double* __restrict__ lnc1,
-                                                      long Np, int Q, int QP, double* __restrict__ PU) {
-  const int W = 2 * QP + 2;
-  const long total = Np * W;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const long n = i / W;
-    const int c = (int)(i - n * W);
-    double v = 0.0;
-    if (c < QP) { if (c < Q) v = mu[n * Q + c]; }
-    else if (c < 2 * QP) { if (c - QP < Q) v = U[n * Q + c - QP]; }
-    else if (c == 2 * QP) v = lnc1[n];
-    PU[i] = v;
   }
 }
 
@@ -365,15 +351,13 @@ int run_prep_and_generate(gp_ctx* c) {
   a.mu = c->mu; a.S = c->S; a.U = c->U; a.lnc1 = c->lnc1; a.Xa = c->Xa; a.klpart = c->klpart;
   a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CXp = c->CXp; a.step = c->step; a.sf2 = c->sf2;
   a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = (c->regime_A && !c->want_emb) ? 1 : 0;
+  a.QP = (c->Q + 1) / 2 * 2; a.PU = a.QP <= 16 ? c->PU : nullptr;
   hipLaunchKernelGGL(prep_elem_kernel, dim3((unsigned)std::min<long>((c->Np * c->Q + 255) / 256, 16384)), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(prep_row_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());
   (void)hipEventRecord(c->ev[8], c->stream);
   const int QP = (c->Q + 1) / 2 * 2;
   if (QP <= 16) {
-    const long total = c->Np * (2L * QP + 2);
-    hipLaunchKernelGGL(pack_pu_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 16384)), dim3(256), 0, c->stream, c->mu, c->U, c->lnc1,
-                       (long)c->Np, c->Q, QP, c->PU);
     switch (QP) {
       case 2: launch_psi1<2>(c); break;
       case 4: launch_psi1<4>(c); break;

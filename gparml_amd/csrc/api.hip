@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace gp {
 thread_local std::string g_create_error;
@@ -147,6 +148,8 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   A(&c->gXmu, (size_t)N_s * Q); A(&c->gXs, (size_t)N_s * Q);
   c->ga_blocks = blocks_for(Np);
   A(&c->gapart, (size_t)c->ga_blocks * Q);
+  A(&c->hgpart, (size_t)((N_s + 255) / 256) * Q);
+  { const char* e = getenv("GP_P2_VARIANT"); c->p2_variant = e ? atoi(e) : 0; }
   A(&c->g_latest, (size_t)2 * N_s * Q); A(&c->g_new, (size_t)2 * N_s * Q); A(&c->g_old, (size_t)2 * N_s * Q);
   for (int i = 0; i < 14 && rc == GP_OK; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) rc = fail(c, GP_ERR_HIP, "hipEventCreate failed");
   if (rc == GP_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(c, GP_ERR_HIP, "device sync failed after allocation");
@@ -162,7 +165,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->U, c->PU, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
-                    c->HZp, c->gXmu, c->gXs, c->gapart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
+                    c->HZp, c->gXmu, c->gXs, c->gapart, c->hgpart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
                     c->Gpart, c->Gtmp, c->gapart2, c->pp};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);

@@ -57,11 +57,13 @@ __global__ void __launch_bounds__(256) prep_elem_kernel(PrepArgs a) {
     const double u = al / (al * s + 1.0);
     a.U[i] = u;
     if (a.PU) { double* rec = a.PU + n * (2 * a.QP + 2); rec[q] = m; rec[a.QP + q] = u; }
-    double f1, f2;
-    if (a.fixedA) { f1 = m; f2 = m * m; } else { f1 = u * m; f2 = u; }
-    if (n >= a.N) { f1 = 0.0; f2 = 0.0; }
-    a.Xa[n * a.CXp + q] = f1;
-    a.Xa[n * a.CXp + a.Q + q] = f2;
+    // per-point features of the n-contraction: fixed embeddings [mu (Q) | 1 | 0 ...], otherwise [u mu (Q) | u (Q) | 1 | 0 ...]
+    if (a.fixedA) {
+      a.Xa[n * a.CXp + q] = (n < a.N) ? m : 0.0;
+    } else {
+      a.Xa[n * a.CXp + q] = (n < a.N) ? u * m : 0.0;
+      a.Xa[n * a.CXp + a.Q + q] = (n < a.N) ? u : 0.0;
+    }
   }
 }
 
@@ -83,8 +85,9 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
     }
     a.lnc1[n] = lnc;
     if (a.PU) a.PU[n * (2 * a.QP + 2) + 2 * a.QP] = lnc;
-    a.Xa[n * a.CXp + 2 * a.Q] = (n < a.N) ? 1.0 : 0.0;
-    for (int c = 2 * a.Q + 1; c < a.CXp; ++c) a.Xa[n * a.CXp + c] = 0.0;
+    const int c1 = a.fixedA ? a.Q : 2 * a.Q;   // column of ones
+    a.Xa[n * a.CXp + c1] = (n < a.N) ? 1.0 : 0.0;
+    for (int c = c1 + 1; c < a.CXp; ++c) a.Xa[n * a.CXp + c] = 0.0;
   }
   red[threadIdx.x] = kl;
   __syncthreads();
@@ -330,6 +333,8 @@ __global__ void p1_scalars_kernel(const double* klpart, int nblocks, double sumY
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+bool p2_fast_mode(const gp_ctx* c);
+
 int run_upload_y(gp_ctx* c, const double* dY) {
   const long total = c->Np * (long)c->Dp;
   const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
@@ -350,7 +355,7 @@ int run_prep_and_generate(gp_ctx* c) {
   a.Xmu = c->Xmu; a.Xs = c->Xs; a.dir = c->have_dir ? c->dir : nullptr; a.alpha = c->alpha;
   a.mu = c->mu; a.S = c->S; a.U = c->U; a.lnc1 = c->lnc1; a.Xa = c->Xa; a.klpart = c->klpart;
   a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CXp = c->CXp; a.step = c->step; a.sf2 = c->sf2;
-  a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = (c->regime_A && !c->want_emb) ? 1 : 0;
+  a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = p2_fast_mode(c) ? 1 : 0;
   a.QP = (c->Q + 1) / 2 * 2; a.PU = a.QP <= 16 ? c->PU : nullptr;
   hipLaunchKernelGGL(prep_elem_kernel, dim3((unsigned)std::min<long>((c->Np * c->Q + 255) / 256, 16384)), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(prep_row_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
@@ -573,107 +578,339 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
   }
 }
 
-// Fast variant for the fixed-embedding regime (no per-point outputs) and CXp <= 4*NRB <= 24: the n-contraction
-// accumulators R[64 m][CXp] of each wave stay in registers across all n tiles of the slice (no read-modify-write), and
-// every epilogue operand comes from LDS: the Xa tile is staged once per tile, the Psi1 tile arrives by coalesced 16-byte
-// loads (prefetched one 16-row slab ahead) and is re-laid out through the wave's slab.
+// Fast variants for the fixed-embedding regime (no per-point outputs), Q + 1 <= 4 * NRB <= 24.  Per-point features are
+// Xa = [mu (Q) | 1 | 0..]: R[m][:] = sum_n W[n][m] Xa[n][:] gives W^T mu and W^T 1 (grad_Z, and the z-dependent terms of
+// grad_alpha); the remaining term of grad_alpha, sum_nm W[n][m] mu_nq^2 = sum_n h_n mu_nq^2, only needs the row sums
+// h_n = sum_m W[n][m], which each wave forms from its accumulator registers (p2_ga_kernel finishes it).  Compared with
+// carrying [mu, mu^2, 1] through the MFMAs this halves the epilogue and the resident R accumulators (no scratch spills).
+// The k-loop runs in rotated order so that the chunks holding the workgroup's own Psi1 columns come last: the epilogue's
+// re-read of that tile then hits the XCD's L2.
+__device__ __forceinline__ double quad_sum(double v) {   // sum over the four lanes l&3 (same accumulator row)
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  return v;
+}
+// every accumulator read below this point is ordered after the drain (the compiler cannot see the MFMAs inside the asm strings)
+__device__ __forceinline__ void acc_fence8(double (&x)[8]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
+__device__ __forceinline__ void acc_fence16(double (&x)[16]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+  asm volatile("" : "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+}
+
 template <int NRB>
 __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
   const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
   if (slice >= p.S) return;
   __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int XS = 4 * NRB;                                     // feature columns staged per point
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int wrow0 = wr * WT, wcol0 = wc * WT;
-  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
-  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4);
-  double* xa_s = &lds[0][0][0];                                   // [128][CXp]   (<= 24.6 KB)
+  double* xa_s = &lds[0][0][0];                                   // [128][XS]   (<= 24.6 KB)
   double* slab = &lds[0][0][0] + TILE * 24 + wave * (16 * SLAB_LD);  // per wave [16][66]
   const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
   const int nc = p.kend - p.kbeg;
   const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
+  int rot = (p.kbeg == 0) ? (mt + 1) * (TILE / KC) : 0;           // first chunk of the rotated k order
+  if (rot >= nc) rot = 0;
   double r[4][NRB];
 #pragma unroll
   for (int am = 0; am < 4; ++am)
 #pragma unroll
     for (int bc = 0; bc < NRB; ++bc) r[am][bc] = 0.0;
-  const int crow = lane & 15, ccg = lane >> 4;                    // slab load: row, 16-column group (8 consecutive lanes -> 8 rows: the
-                                                                  // 16-byte LDS stores of a lane group hit 32 distinct banks)
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
     const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;
     Acc acc;
     acc.zero();
-    tile_dma<K_CONTIG>(lds[0][0], Ab, p.ld, wave, lane);
-    tile_dma<FREE_CONTIG>(lds[0][1], Bb, p.Mp, wave, lane);
+    int kc = rot;
+    tile_dma<K_CONTIG>(lds[0][0], Ab + (long)kc * KC, p.ld, wave, lane);
+    tile_dma<FREE_CONTIG>(lds[0][1], Bb + (long)kc * KC * p.Mp, p.Mp, wave, lane);
     dma_wait();
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
       const int cur = c & 1;
       if (c + 1 < nc) {
-        tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
-        tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
+        kc = (kc + 1 == nc) ? 0 : kc + 1;
+        int ld_ = lane;
+        asm volatile("" : "+v"(ld_));                             // DMA addressing recomputed per chunk instead of held in registers
+        tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)kc * KC, p.ld, wave, ld_);
+        tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)kc * KC * p.Mp, p.Mp, wave, ld_);
       }
       mma_chunk_lo<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
       dma_wait();
       __syncthreads();
     }
     mfma_drain(acc.v[3][15]);
-    // ---- epilogue: all staging buffers are free now
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) acc_fence16(acc.v[ar]);
+    // ---- epilogue: all staging buffers are free now.  Its addressing comes from an OPAQUE copy of the lane id so that
+    // none of it stays live across the k-loop (as loop invariants these values were spilled to scratch).
+    int le = tid;
+    asm volatile("" : "+v"(le));
+    const int e_lane = le & 63;
+    const int lr = e_lane & 15, lk = e_lane >> 4, lj = e_lane & 3;
+    const int srow = 4 * ((e_lane >> 2) & 3) + (e_lane >> 4);
+    const int crow = e_lane & 15, ccg = e_lane >> 4;              // slab load: row, 16-column group (8 consecutive lanes -> 8 rows: the
+                                                                  // 16-byte LDS stores of a lane group hit 32 distinct banks)
     {
       const double2* src = reinterpret_cast<const double2*>(p.Xa + n0 * p.CXp);
       double2* dst = reinterpret_cast<double2*>(xa_s);
-      const int n2 = TILE * p.CXp / 2;
-      for (int i = tid; i < n2; i += 256) dst[i] = src[i];
+      for (int i = le; i < TILE * (XS / 2); i += 256) { const int row = i / (XS / 2), c2 = i - row * (XS / 2); dst[i] = src[(long)row * (p.CXp / 2) + c2]; }
     }
     const double* kbase = p.Kaug + (n0 + wrow0 + crow) * p.ld + (long)mt * TILE + wcol0 + 16 * ccg;
-    double2 kv[8];
+    double kv[16];     // plain doubles: an array of double2 stays in scratch memory (hipcc does not promote it to registers)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const double2*>(kbase + 2 * i);
+    for (int i = 0; i < 8; ++i) { const double2 t = *reinterpret_cast<const double2*>(kbase + 2 * i); kv[2 * i] = t.x; kv[2 * i + 1] = t.y; }
     __syncthreads();   // xa_s visible to every wave
+    double* hout = p.HZp + (long)(mt * 2 + wc) * p.Np + n0 + wrow0 + srow;   // row sums of W over this wave's 64 columns
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(slab + crow * SLAB_LD + 16 * ccg + 2 * i) = kv[i];
+      for (int i = 0; i < 8; ++i) { double2 t; t.x = kv[2 * i]; t.y = kv[2 * i + 1]; *reinterpret_cast<double2*>(slab + crow * SLAB_LD + 16 * ccg + 2 * i) = t; }
       if (ar < 3) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const double2*>(kbase + (long)(16 * (ar + 1)) * p.ld + 2 * i);
+        for (int i = 0; i < 8; ++i) { const double2 t = *reinterpret_cast<const double2*>(kbase + (long)(16 * (ar + 1)) * p.ld + 2 * i); kv[2 * i] = t.x; kv[2 * i + 1] = t.y; }
       }
+      double hs = 0.0;
 #pragma unroll
       for (int bc = 0; bc < 16; ++bc) {
         const double w = acc.v[ar][bc] * slab[srow * SLAB_LD + 4 * bc + lj];
         slab[srow * SLAB_LD + 4 * bc + lj] = w;    // each lane overwrites exactly the element it read
+        hs += w;
       }
-      const double* xrow = xa_s + (wrow0 + 16 * ar) * p.CXp + lj;
+      hs = quad_sum(hs);
+      if (lj == 0) hout[16 * ar] = hs;
+      const double* xrow = xa_s + (wrow0 + 16 * ar) * XS + lj;
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
         double a[4], b[NRB];
 #pragma unroll
         for (int am = 0; am < 4; ++am) a[am] = slab[(4 * k4 + lk) * SLAB_LD + 16 * am + lr];
 #pragma unroll
-        for (int bc = 0; bc < NRB; ++bc) b[bc] = xrow[(4 * k4 + lk) * p.CXp + 4 * bc];   // CXp == 4 * NRB
+        for (int bc = 0; bc < NRB; ++bc) b[bc] = xrow[(4 * k4 + lk) * XS + 4 * bc];
 #pragma unroll
         for (int am = 0; am < 4; ++am)
 #pragma unroll
           for (int bc = 0; bc < NRB; ++bc) mfma444_acc(r[am][bc], a[am], b[bc]);
       }
     }
-    mfma_drain(r[3][NRB - 1]);   // hipcc may spill r[] around the k-loop: its MFMAs must have retired first
+    mfma_drain(r[3][NRB - 1]);
     __syncthreads();   // slabs / xa_s live in the staging buffers the next tile's DMA overwrites
   }
-  double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
+  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4), lj = lane & 3;
+  double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * XS;
 #pragma unroll
   for (int am = 0; am < 4; ++am)
 #pragma unroll
     for (int bc = 0; bc < NRB; ++bc) {
-      Rmine[(long)(16 * am + srow) * p.CXp + 4 * bc + lj] = (t1 > t0) ? r[am][bc] : 0.0;
+      Rmine[(long)(16 * am + srow) * XS + 4 * bc + lj] = (t1 > t0) ? r[am][bc] : 0.0;
     }
 }
 
+// Eight-wave variant (4 * NRB <= 12, i.e. Q <= 11 -- BASELINE configs[1..3]): the same 128 x 128 workgroup tile with every 64 x 64
+// quadrant shared by two waves (64 rows x 32 columns: 32 accumulators), four waves per SIMD, and an epilogue that touches
+// no global memory from registers: the workgroup's Psi1 tile arrives by LDS-DMA in four 16-row slabs per wave (the first
+// one and the tile's Xa rows travel during the last k-chunk, the others while the previous slab is processed), W = G o Psi1
+// overwrites the slab in place, and the same slab is read back transposed as the MFMA A operand.  The slab image is
+// permuted through the DMA's SOURCE address -- 16-byte pair p of slab row r sits at pair p ^ 2 g(r),
+// g(r) = ((r & 1) << 2) | ((r >> 2) & 3) -- so that the accumulator-layout accesses (8 rows x 4 columns per 32-lane group)
+// and the transposed operand reads (2 rows x 16 columns) are both free of bank conflicts.
+// LDS map (doubles): buf0 [0, 4608) | buf1 [4608, 9216) | extra [9216, 10240).  The last k-chunk always computes from buf0, so
+// slab set A (8 waves x 512) + the Xa tile (128 x 4 NRB) occupy buf1 + extra, and slab set B goes to buf0 after the loop.
+constexpr int P2W8_LDS = 10240;
+__device__ __forceinline__ int slab_g(int r) { return ((r & 1) << 2) | ((r >> 2) & 3); }
+
+template <int NRB>
+__global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
+  if (slice >= p.S) return;
+  __shared__ __attribute__((aligned(16))) double lds[P2W8_LDS];
+  constexpr int XS = 4 * NRB;
+  static_assert(4096 + TILE * XS <= 4608 + 1024, "Xa tile does not fit next to slab set A");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave & 3, half = wave >> 2;
+  const int wr = quad >> 1, wc = quad & 1;
+  const int wrow0 = wr * WT, wcol0 = wc * WT + 32 * half;
+  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
+  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
+  const int nc = p.kend - p.kbeg;
+  const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
+  int rot = (p.kbeg == 0) ? (mt + 1) * (TILE / KC) : 0;
+  if (rot >= nc) rot = 0;
+  double* const setA = lds + 4608 + wave * 512;
+  double* const setB = lds + wave * 512;
+  double* const xa_s = lds + 4608 + 4096;
+  double r[2][NRB];
+#pragma unroll
+  for (int am = 0; am < 2; ++am)
+#pragma unroll
+    for (int g = 0; g < NRB; ++g) r[am][g] = 0.0;
+  // chunk staging: 16 DMA instructions per operand tile, two per wave; lane offsets are 32-bit (uniform base + offset addressing)
+  auto chunk_dma = [&](double* buf, const double* a, const double* b) {
+    int ld_ = lane;
+    asm volatile("" : "+v"(ld_));                             // recomputed per chunk (a handful of integer ops) instead of held in registers
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int I = wave * 2 + i;
+      const int row = swap03(I * 8 + (ld_ >> 3));
+      glds16(a + (unsigned)(row * (int)p.ld + 2 * ((ld_ & 7) ^ (row & 7))), buf + I * 8 * KC);
+      glds16(b + (long)I * p.Mp + 2u * ld_, buf + TILE_LDS_DOUBLES + I * LDS_RC);
+    }
+  };
+  // Epilogue addressing is derived from an OPAQUE copy of the lane id at its point of use: as loop invariants these values
+  // would stay live across the k-loop and push the kernel over its 128 registers (scratch spills).
+  struct Epi { int lr, lk, lj, srow, sg, sbase, abase, aflip, dpair; };
+  auto epi = [&]() {
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    Epi e;
+    e.lr = le & 15; e.lk = le >> 4; e.lj = le & 3;
+    e.srow = 4 * ((le >> 2) & 3) + (le >> 4);
+    // slab addressing (doubles): accumulator layout (row srow, column 4 bc + lj) -> srow*32 + 4*(bc ^ g(srow)) + lj
+    e.sg = slab_g(e.srow);
+    e.sbase = e.srow * 32 + e.lj;
+    // operand reads (row 4 k4 + lk, column 16 am + lr) -> (4 k4 + lk)*32 + 2*(((am ^ (lk & 1)) << 3) | ((lr >> 1) ^ (2 k4))) + (lr & 1)
+    e.abase = e.lk * 32 + (e.lr & 1) + 16 * (e.lk & 1);     // am = 0; am = 1 adds aflip
+    e.aflip = 16 - 32 * (e.lk & 1);
+    // slab DMA source: instruction i moves slab rows 4 i + (lane >> 4); lane & 15 = physical pair, g(4 i + lk) = ((lk & 1) << 2) | i
+    e.dpair = (le & 15) ^ ((e.lk & 1) << 3);
+    return e;
+  };
+  auto slab_dma = [&](const Epi& e, const double* Ktile, int ar, double* slab) {   // Ktile: row 0, column 0 of the wave's Psi1 block
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      glds16(Ktile + (unsigned)((16 * ar + 4 * i + e.lk) * (int)p.ld + 2 * (e.dpair ^ (2 * i))), slab + i * 128);
+  };
+  for (int nt = t0; nt < t1; ++nt) {
+    const long n0 = (long)nt * TILE;
+    const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
+    const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;
+    double acc[4][8];
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[ar][j] = 0.0;
+    int kc = rot;
+    const int b0 = (nc + 1) & 1;                                // buffer of chunk 0; chunk c uses (c + nc + 1) & 1, the last one buf0
+    chunk_dma(lds + b0 * 4608, Ab + (long)kc * KC, Bb + (long)kc * KC * p.Mp);
+    dma_wait();
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      const int cur = (c + nc + 1) & 1;
+      if (c + 1 < nc) {
+        kc = (kc + 1 == nc) ? 0 : kc + 1;
+        chunk_dma(lds + (cur ^ 1) * 4608, Ab + (long)kc * KC, Bb + (long)kc * KC * p.Mp);
+      } else {
+        // last chunk (computing from buf0): slab 0 of this wave and the tile's Xa rows into buf1 + extra
+        const Epi e0 = epi();
+        slab_dma(e0, Ab - (long)p.kbeg * KC + (long)wrow0 * p.ld + (long)mt * TILE + wcol0, 0, setA);
+        for (int I = wave; I < TILE * XS / 128; I += 8) {       // 128 doubles (64 x 16 B) per instruction
+          const int piece = I * 64 + lane;                      // 16-byte piece of the compact [128][XS] tile
+          const int row = piece / (XS / 2), c2 = piece - row * (XS / 2);
+          glds16(p.Xa + (n0 + row) * p.CXp + 2 * c2, xa_s + I * 128);
+        }
+      }
+      const double* sA = lds + cur * 4608;
+      const double* sB = sA + TILE_LDS_DOUBLES;
+#pragma unroll
+      for (int k4 = 0; k4 < KC / 4; ++k4) {
+        double a[4], b[8];
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) a[ar] = sA[ofs.a[k4] + 256 * ar];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = sB[ofs.b[0] + 4 * k4 * LDS_RC + 4 * j];
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mfma444_acc(acc[ar][j], a[ar], b[j]);
+      }
+      dma_wait();
+      __syncthreads();
+    }
+    const Epi e = epi();
+    const double* Ktile = p.Kaug + (n0 + wrow0) * p.ld + (long)mt * TILE + wcol0;
+    slab_dma(e, Ktile, 1, setB);           // buf0 is free now
+    mfma_drain(acc[3][7]);
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);
+    double hsum[4];
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) {
+      double* slab = (ar & 1) ? setB : setA;
+      if (ar < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // slab ar has landed; slab ar + 1 (4 DMAs) may still fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      double hs = 0.0;
+#pragma unroll
+      for (int bc = 0; bc < 8; ++bc) {
+        const int idx = e.sbase + 4 * (bc ^ e.sg);
+        const double w = acc[ar][bc] * slab[idx];
+        slab[idx] = w;
+        hs += w;
+      }
+      hsum[ar] = quad_sum(hs);     // stored after the last slab: a store in between would blur the vmcnt accounting of the DMAs
+      const double* xrow = xa_s + (wrow0 + 16 * ar + e.lk) * XS + e.lj;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        double a[2], b[NRB];
+        const int ai = e.abase + 128 * k4 + 2 * ((e.lr >> 1) ^ (2 * k4));
+        a[0] = slab[ai];
+        a[1] = slab[ai + e.aflip];
+#pragma unroll
+        for (int g = 0; g < NRB; ++g) b[g] = xrow[4 * k4 * XS + 4 * g];
+#pragma unroll
+        for (int am = 0; am < 2; ++am)
+#pragma unroll
+          for (int g = 0; g < NRB; ++g) mfma444_acc(r[am][g], a[am], b[g]);
+      }
+      if (ar < 2) {
+        // this slab buffer is free again (its reads were consumed by the MFMAs above): slab ar + 2
+        __builtin_amdgcn_sched_barrier(0);
+        slab_dma(e, Ktile, ar + 2, slab);
+      }
+    }
+    if (e.lj == 0) {
+      double* hout = p.HZp + (long)(mt * 4 + wc * 2 + half) * p.Np + n0 + wrow0 + e.srow;
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar) hout[16 * ar] = hsum[ar];
+    }
+    mfma_drain(r[1][NRB - 1]);
+    __syncthreads();   // slabs / xa_s live in the staging buffers the next tile's DMA overwrites
+  }
+  double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * XS;
+#pragma unroll
+  for (int am = 0; am < 2; ++am)
+#pragma unroll
+    for (int g = 0; g < NRB; ++g) Rmine[(long)(16 * am + srow) * XS + 4 * g + lj] = (t1 > t0) ? r[am][g] : 0.0;
+}
+
+// grad_alpha's mu^2 term from the row sums: out[block][q] = -1/2 sum_{n in block} (sum_p H[p][n]) mu_nq^2   (fixed tree)
+__global__ void __launch_bounds__(256) p2_ga_kernel(const double* __restrict__ H, int nparts, long N, long Np, int Q,
+                                                    const double* __restrict__ mu, double* __restrict__ gapart) {
+  __shared__ double red[256];
+  __shared__ double hsum[256];
+  const long n = blockIdx.x * 256L + threadIdx.x;
+  double h = 0.0;
+  if (n < N) for (int i = 0; i < nparts; ++i) h += H[(long)i * Np + n];
+  hsum[threadIdx.x] = h;
+  for (int q = 0; q < Q; ++q) {
+    const double m = (n < N) ? mu[n * Q + q] : 0.0;
+    red[threadIdx.x] = -0.5 * h * m * m;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) gapart[(long)blockIdx.x * Q + q] = red[0];
+    __syncthreads();
+  }
+}
+
 // R = sum of the (slice, wave-row) partials; then the data parts of grad_Z / grad_alpha
-//   fixedA (Xa = [mu, mu^2, 1]):  gZ = a (R1 - Z R0),  ga = -1/2 sum_m (R2 - 2 Z R1 + Z^2 R0)      [regime A, fixed embeddings]
+//   fixedA (Xa = [mu, 1]):  gZ = a (R1 - Z R0),  ga = -1/2 sum_m (-2 Z R1 + Z^2 R0) + p2_ga_kernel's mu^2 term   [regime A, fixed embeddings]
 //   general (Xa = [u mu, u, 1]):  gZ = R1 - Z R2'  with R1 = W^T(u mu), R2' = W^T u; ga comes from the per-point kernel
 __global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict__ Rpart, int nparts, int Mp, int CXp, int M, int Q,
                                                         const double* __restrict__ Z, const double* __restrict__ alpha, int fixedA,
@@ -696,9 +933,9 @@ __global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict
   for (int q = threadIdx.x; q < Q; q += 256) {
     const double z = Z[(long)m * Q + q];
     if (fixedA) {
-      const double r1 = R[q], r2 = R[Q + q], r0 = R[2 * Q];
+      const double r1 = R[q], r0 = R[Q];
       gZ[(long)m * Q + q] = alpha[q] * (r1 - z * r0);
-      gapart[(long)m * Q + q] = -0.5 * (r2 - 2.0 * z * r1 + z * z * r0);
+      gapart[(long)m * Q + q] = -0.5 * (z * z * r0 - 2.0 * z * r1);
     } else {
       gZ[(long)m * Q + q] = R[q] - z * R[Q + q];
       gapart[(long)m * Q + q] = 0.0;
@@ -748,8 +985,12 @@ __global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, const d
   if (threadIdx.x == 0) out[q] = red[0];
 }
 
+// fixed-embedding fast path: regime A without embedding gradients and Q + 1 <= 24 feature columns
+bool p2_fast_mode(const gp_ctx* c) { return c->regime_A && !c->want_emb && c->Q + 1 <= 24; }
+
 int run_phase2(gp_ctx* c) {
-  const bool ppath = !(c->regime_A && !c->want_emb);
+  const bool fast = p2_fast_mode(c);
+  const bool ppath = !fast;
   P2Args p;
   p.Kaug = c->Kaug; p.ld = c->LDK; p.Bm = c->Bm; p.Xa = c->Xa; p.Zaug = c->Zaug; p.Rpart = c->Rpart; p.HZp = c->HZp;
   p.Mp = c->Mp; p.CXp = c->CXp; p.CZp = c->CZp; p.MT = c->Mp / TILE; p.Np = c->Np;
@@ -761,12 +1002,20 @@ int run_phase2(gp_ctx* c) {
   p.kbeg = c->regime_A ? 0 : c->Mp / KC;
   p.kend = (c->Mp + (int)round_up(c->D, KC)) / KC;   // chunks beyond the last real Y column are all zero
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
+  const int nrb = (c->Q + 1 + 3) / 4;                // fast path: feature columns [mu (Q) | 1] in groups of four
+  int hparts = 0;                                    // row-sum partial arrays the fast kernels leave in HZp
   (void)hipEventRecord(c->ev[12], c->stream);
-  const bool fast = !ppath && c->CXp <= 24;
   if (ppath) hipLaunchKernelGGL((p2_kernel<true>), dim3(blocks), dim3(256), 0, c->stream, p);
-  else if (!fast) hipLaunchKernelGGL((p2_kernel<false>), dim3(blocks), dim3(256), 0, c->stream, p);
-  else {
-    switch (c->CXp / 4) {
+  else if (nrb <= 3 && c->p2_variant != 4) {
+    hparts = 4 * p.MT;
+    switch (nrb) {
+      case 1: hipLaunchKernelGGL((p2_fast8_kernel<1>), dim3(blocks), dim3(512), 0, c->stream, p); break;
+      case 2: hipLaunchKernelGGL((p2_fast8_kernel<2>), dim3(blocks), dim3(512), 0, c->stream, p); break;
+      default: hipLaunchKernelGGL((p2_fast8_kernel<3>), dim3(blocks), dim3(512), 0, c->stream, p); break;
+    }
+  } else {
+    hparts = 2 * p.MT;
+    switch (nrb) {
       case 1: hipLaunchKernelGGL((p2_fast_kernel<1>), dim3(blocks), dim3(256), 0, c->stream, p); break;
       case 2: hipLaunchKernelGGL((p2_fast_kernel<2>), dim3(blocks), dim3(256), 0, c->stream, p); break;
       case 3: hipLaunchKernelGGL((p2_fast_kernel<3>), dim3(blocks), dim3(256), 0, c->stream, p); break;
@@ -780,8 +1029,8 @@ int run_phase2(gp_ctx* c) {
   double* gZ = c->grads;
   double* ga = c->grads + (long)c->M * c->Q;
   // T2 is free after the global step: per-row alpha partials [M][Q]
-  hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(256), 0, c->stream, c->Rpart, 2 * S, c->Mp, c->CXp, c->M, c->Q, c->Z, c->alpha,
-                     ppath ? 0 : 1, gZ, c->T2);
+  hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(256), 0, c->stream, c->Rpart, 2 * S, c->Mp, fast ? 4 * nrb : c->CXp, c->M, c->Q, c->Z,
+                     c->alpha, fast ? 1 : 0, gZ, c->T2);
   GP_HIP(c, hipGetLastError());
   if (ppath) {
     PtArgs a;
@@ -791,7 +1040,10 @@ int run_phase2(gp_ctx* c) {
     GP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->gapart, c->ga_blocks, c->Q, ga);
   } else {
-    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, (const double*)nullptr, 0, c->Q, ga);
+    const int hb = (int)((c->N + 255) / 256);        // <= ga_blocks' allocation? gapart holds ga_blocks*Q; use klpart-sized buffer instead
+    hipLaunchKernelGGL(p2_ga_kernel, dim3(hb), dim3(256), 0, c->stream, c->HZp, hparts, (long)c->N, (long)c->Np, c->Q, c->mu, c->hgpart);
+    GP_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->hgpart, hb, c->Q, ga);
   }
   GP_HIP(c, hipGetLastError());
   return GP_OK;

@@ -81,19 +81,62 @@ SHAPES = [
 ]
 
 
+def _check(out, ref, regime, emb):
+    assert_close(out['stats']['Psi2'], ref['stats']['sum_exp_K_mi_K_im'], 1e-11, what='Psi2')
+    assert_close(out['stats']['C'], ref['stats']['exp_K_miY'], 1e-11, what='C')
+    assert_close(out['F'], ref['F'], F_RTOL, what='F')
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta') + (('grad_X_mu',) if emb else ()):
+        assert_close(out[k], ref[k], G_RTOL, what=k)
+    if regime == 'B' and emb:
+        assert_close(out['grad_X_S'], ref['grad_X_S'], G_RTOL, what='grad_X_S')
+
+
 @pytest.mark.parametrize('N,D,M,Q,regime,alpha', SHAPES)
 def test_against_oracle_on_seeded_inputs(N, D, M, Q, regime, alpha):
     from oracle import factorised as Fz
     d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=11, zseed=12, alpha_value=alpha)
     ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
     out = _run(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
-    assert_close(out['stats']['Psi2'], ref['stats']['sum_exp_K_mi_K_im'], 1e-11, what='Psi2')
-    assert_close(out['stats']['C'], ref['stats']['exp_K_miY'], 1e-11, what='C')
-    assert_close(out['F'], ref['F'], F_RTOL, what='F')
-    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu'):
-        assert_close(out[k], ref[k], G_RTOL, what=k)
-    if regime == 'B':
-        assert_close(out['grad_X_S'], ref['grad_X_S'], G_RTOL, what='grad_X_S')
+    _check(out, ref, regime, True)
+
+
+# Fixed embeddings (want_embedding_grads = 0): the kernel sequence bench.py times -- p1_kernel8, global step, the fast phase-2
+# kernels (eight-wave p2_fast8_kernel for Q <= 11, four-wave p2_fast_kernel<NRB> up to Q = 23, general kernel beyond).
+FIXED_SHAPES = [s for s in SHAPES if s[4] == 'A'] + [(1500, 6, 200, 11, 'A', 0.2), (700, 5, 140, 12, 'A', 0.2), (600, 4, 70, 23, 'A', 0.1),
+                                                     (500, 3, 40, 24, 'A', 0.1)]
+
+
+@pytest.mark.parametrize('N,D,M,Q,regime,alpha', FIXED_SHAPES)
+def test_fixed_embeddings_against_oracle(N, D, M, Q, regime, alpha):
+    from oracle import factorised as Fz
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=21, zseed=22, alpha_value=alpha)
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=False)
+    out = _run(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], emb=False)
+    _check(out, ref, regime, False)
+
+
+@pytest.mark.parametrize('regime,emb', [('A', False), ('A', True), ('B', True)])
+def test_config1_full_evaluation(regime, emb):
+    """BASELINE configs[1] at its full size (N=1e5, D=10, M=128, Q=10, alpha = 1/Q): bound and every gradient against the oracle."""
+    from oracle import factorised as Fz
+    N, D, M, Q = 100000, 10, 128, 10
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=0, zseed=1, alpha_value=0.1)
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=emb)
+    out = _run(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], emb=emb)
+    _check(out, ref, regime, emb)
+
+
+def test_config4_shape():
+    """BASELINE configs[4]'s per-GPU shape (D=1000, M=1024, Q=50, free embeddings) at an N the oracle finishes in a minute:
+    16 inducing slabs / 32 strips of the wide-latent MFMA pair kernels, eight 128-column Y tiles, two and a half row tiles."""
+    from oracle import factorised as Fz
+    N, D, M, Q = 320, 1000, 1024, 50
+    rs = np.random.RandomState(5)
+    d = Fz.synthetic_shard(N, D, 64, Q, regime='B', seed=4, zseed=5, alpha_value=0.02)
+    d['Z'] = d['X_mu'][rs.randint(0, N, size=M)] + 0.3 * rs.randn(M, Q)      # M > N: inducing points around re-used rows
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+    out = _run(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+    _check(out, ref, 'B', True)
 
 
 def test_errors_map_to_reference_exceptions():

@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+P2_KERNEL = 'gp::p2_fast8_kernel<3>'   # the dominant kernel at the default configuration (Q = 10: three feature groups)
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 (vector = matrix); ubench ceiling 74 (profiles/r01_ubench_f64_mfma4x4x4.txt)
 
 
@@ -71,9 +72,20 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=200000)
     a = ap.parse_args()
 
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks as a fresh torchrun child (nothing has touched the GPU yet)
+            import socket
+            import subprocess
+            sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+                   '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d; launch as\n  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (a.gpus, world, a.gpus, a.gpus))
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
@@ -124,15 +136,20 @@ def main():
 
     if rank == 0:
         N, D, M, Q = a.N, a.D, a.M, a.Q
-        # algorithmic FLOPs (FMA = 2) of the dominant kernel p2_kernel: K.(2 Bbar) 2NM^2 + Y.Abar^T 2NMD + the
-        # n-contraction with [mu, mu^2, 1]: 2NM(2Q+1)   
-        flops_p2 = 2.0 * N * M * (M + D) + 2.0 * N * M * (2 * Q + 1)
+        # algorithmic FLOPs (FMA = 2) of the dominant kernel, the fast phase-2 kernel: K.(2 Bbar) 2NM^2 + Y.Abar^T 2NMD + the
+        # n-contraction W^T [mu, 1]: 2NM(Q+1)   (the mu^2 term of grad_alpha only needs row sums)
+        flops_p2 = 2.0 * N * M * (M + D) + 2.0 * N * M * (Q + 1)
         ach = flops_p2 / (kern['p2_kernel_ms'] * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes per launch of that kernel from the PMC passes of the SAME command (tools/r02_prof.sh -> profiles/traffic.json,
+        # FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes); quoted only while it describes the kernel that ran here
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get('p2_kernel_hbm_bytes_per_launch')
+                tj = json.load(open(tf))
+                if tj.get('kernel') == P2_KERNEL and (tj.get('N'), tj.get('D'), tj.get('M'), tj.get('Q')) == (N, D, M, Q):
+                    traffic = tj.get('p2_kernel_hbm_bytes_per_launch')
+                    traffic_src = {'file': 'profiles/traffic.json', 'commit': tj.get('commit'), 'date': tj.get('date')}
             except Exception:
                 traffic = None
         W_eval = float(N) * M * (3.0 * M + 4.0 * D + 12.0 * Q)      # SURVEY.md 8(d) regime-A figure for a whole evaluation
@@ -146,8 +163,8 @@ def main():
                        'points_per_sec': world * N * a.steps / dt, 'F': out['F'],
                        'device_ms': {k: round(v, 4) for k, v in kern.items()},
                        'eval_flops_survey_8d': W_eval, 'eval_fraction_of_fp64_peak': W_eval / (kern['total_ms'] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-            'roofline': {'bound': 'mfma', 'kernel': 'gp::p2_fast_kernel<6>', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / FP64_PEAK_TFLOPS, 'traffic': traffic},
+            'roofline': {'bound': 'mfma', 'kernel': P2_KERNEL, 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src},
         }
         if a.regime == 'B':
             # not the metric's configuration: the free-embedding (Bayesian GPLVM) variant of the same size.  The pair kernels

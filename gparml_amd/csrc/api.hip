@@ -148,8 +148,8 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   A(&c->gXmu, (size_t)N_s * Q); A(&c->gXs, (size_t)N_s * Q);
   c->ga_blocks = blocks_for(Np);
   A(&c->gapart, (size_t)c->ga_blocks * Q);
-  A(&c->hgpart, (size_t)((N_s + 255) / 256) * Q);
-  { const char* e = getenv("GP_P2_VARIANT"); c->p2_variant = e ? atoi(e) : 0; }
+  // fast phase 2: per-wave (eight-wave kernel: blocks * 8 rows of <= 12) or per-256-points (four-wave kernel) partials of grad_alpha's mu^2 term
+  A(&c->hgpart, std::max((size_t)((N_s + 255) / 256) * Q, (size_t)8 * (c->p2_slices + 8) * (Mp / TILE) * 8 * 12));
   A(&c->g_latest, (size_t)2 * N_s * Q); A(&c->g_new, (size_t)2 * N_s * Q); A(&c->g_old, (size_t)2 * N_s * Q);
   for (int i = 0; i < 14 && rc == GP_OK; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) rc = fail(c, GP_ERR_HIP, "hipEventCreate failed");
   if (rc == GP_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(c, GP_ERR_HIP, "device sync failed after allocation");

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
     dma_wait();
     __syncthreads();
   }
-  mfma_drain(acc.v[3][15]);
+  acc.drain();
   if (p.splits > 1) {
     // raw partial tile, [z][by][bx][split][128*128]
     double* w = p.ws + ((((long)bz * gridDim.y + by) * gridDim.x + bx) * p.splits + sp) * (TILE * TILE);

@@ -110,8 +110,7 @@ struct gp_ctx {
   double* gXs = nullptr;      // [N][Q]
   double* gapart = nullptr;   // [blocks][Q] per-block alpha partial sums from the per-point kernel
   int ga_blocks = 0;
-  double* hgpart = nullptr;   // [ceil(N/256)][Q] per-block partial sums of the fast path's mu^2 term of grad_alpha (p2_ga_kernel)
-  int p2_variant = 0;         // development switch (GP_P2_VARIANT): 4 = four-wave fast kernel even when the eight-wave one applies
+  double* hgpart = nullptr;   // partial sums of the fast path's mu^2 term of grad_alpha (per wave, or per 256 points from p2_ga_kernel)
   // regime B (variances > 0): pairwise psi2 kernels; allocated on first use
   bool b_alloc = false;
   double* LE = nullptr;       // [Np][Mp]  1/2 ln c2_n - 1/2 sum_q w_nq (mu_nq - z_mq)^2   (n-major)

@@ -8,6 +8,12 @@
 
 namespace gp {
 
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
+
 // ------------------------------------------------------------------------------------------------ Y upload
 // Kaug[n][Mp + d] = Y[n][d] (zero padded); one block per row group
 __global__ void __launch_bounds__(256) copy_y_kernel(const double* __restrict__ Y, double* __restrict__ Kaug, long N, long Np, int D,
@@ -218,7 +224,7 @@ __global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
     dma_wait();
     __syncthreads();
   }
-  mfma_drain(acc.v[3][15]);
+  acc.drain();
   double* out = p.part + ((long)slice * p.T + type) * (TILE * TILE);
 #pragma unroll
   for (int ar = 0; ar < 4; ++ar)
@@ -267,25 +273,28 @@ __global__ void __launch_bounds__(512, 4) p1_kernel8(P1Args p) {
     const int cur = c & 1;
     if (c + 1 < nc) dma(cur ^ 1, Ab + (long)(c + 1) * step, Bb + (long)(c + 1) * step);
     if (!skip) {
-      const double* sA = lds[cur][0];
-      const double* sB = lds[cur][1];
-#pragma unroll
-      for (int k4 = 0; k4 < KC / 4; ++k4) {
+      // operand reads as explicit ds_read_b64 (mma_f64.h): twice the LDS rate of the ds_read2_b64 pairs hipcc would form
+      const unsigned aA = lds_byte_addr(lds[cur][0]) + 8u * (unsigned)aofs;
+      const unsigned aB = lds_byte_addr(lds[cur][1]) + 8u * (unsigned)bofs;
+      static_for<0, KC / 4>([&](auto k4c) {
+        constexpr int k4 = decltype(k4c)::value;
         double a[4], b[8];
+        static_for<0, 4>([&](auto ic) { constexpr int ar = decltype(ic)::value; a[ar] = ds_read64<k4 * 4 * LDS_RC * 8 + 128 * ar>(aA); });
+        static_for<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<k4 * 4 * LDS_RC * 8 + 32 * j>(aB); });
+        static_for<0, 8>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          lgkm_wait<7 - j>();
 #pragma unroll
-        for (int ar = 0; ar < 4; ++ar) a[ar] = sA[aofs + 4 * k4 * LDS_RC + 16 * ar];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = sB[bofs + 4 * k4 * LDS_RC + 4 * j];
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) mfma444_acc(acc[ar][j], a[ar], b[j]);
-      }
+          for (int ar = 0; ar < 4; ++ar) mfma444_acc(acc[ar][j], a[ar], b[j]);
+        });
+      });
     }
     dma_wait();
     __syncthreads();
   }
   mfma_drain(acc[3][7]);
+#pragma unroll
+  for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);
   double* out = p.part + ((long)slice * p.T + type) * (TILE * TILE);
 #pragma unroll
   for (int ar = 0; ar < 4; ++ar)
@@ -456,6 +465,7 @@ struct P2Args {
   const double* Kaug; long ld; const double* Bm; const double* Xa; const double* Zaug;
   double* Rpart; double* HZp;
   int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend; long Np;
+  double* gapart;   // eight-wave fast kernel: [blocks * 8][4 NRB] per-wave partials of grad_alpha's mu^2 term
 };
 
 constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
@@ -498,7 +508,7 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
       dma_wait();
       __syncthreads();
     }
-    mfma_drain(acc.v[3][15]);
+    acc.drain();
     // W = G o Psi1 (same element positions as the accumulators)
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) {
@@ -532,6 +542,8 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
         }
       }
       mfma_drain(r[3][GRP - 1]);
+#pragma unroll
+      for (int am = 0; am < 4; ++am) acc_fence<GRP>(r[am]);
       // this wave owns rows [wcol0, wcol0+64) of its (slice, wave-row, m-tile) block of Rpart: plain read-modify-write
 #pragma unroll
       for (int am = 0; am < 4; ++am)
@@ -566,6 +578,7 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
             }
           }
           mfma_drain(h[GRP - 1]);
+          acc_fence<GRP>(h);
 #pragma unroll
           for (int bc = 0; bc < GRP; ++bc) {
             const int col = 4 * (GRP * g + bc) + lj;
@@ -583,22 +596,14 @@ __global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
 // grad_alpha); the remaining term of grad_alpha, sum_nm W[n][m] mu_nq^2 = sum_n h_n mu_nq^2, only needs the row sums
 // h_n = sum_m W[n][m], which each wave forms from its accumulator registers (p2_ga_kernel finishes it).  Compared with
 // carrying [mu, mu^2, 1] through the MFMAs this halves the epilogue and the resident R accumulators (no scratch spills).
-// The k-loop runs in rotated order so that the chunks holding the workgroup's own Psi1 columns come last: the epilogue's
-// re-read of that tile then hits the XCD's L2.
+// (Running the k-loop in rotated order, own Psi1 columns last, so that the epilogue's re-read of that tile hits L2 was tried
+// and dropped: the four m-tile workgroups of a slice then stream different k-chunks at any moment and stop sharing the slice's
+// rows in L2 -- fabric traffic 15 -> 25 GB per launch, +0.37 ms.)
 __device__ __forceinline__ double quad_sum(double v) {   // sum over the four lanes l&3 (same accumulator row)
   v += __shfl_xor(v, 1);
   v += __shfl_xor(v, 2);
   return v;
 }
-// every accumulator read below this point is ordered after the drain (the compiler cannot see the MFMAs inside the asm strings)
-__device__ __forceinline__ void acc_fence8(double (&x)[8]) {
-  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
-}
-__device__ __forceinline__ void acc_fence16(double (&x)[16]) {
-  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
-  asm volatile("" : "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
-}
-
 template <int NRB>
 __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -614,8 +619,6 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
   const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
   const int nc = p.kend - p.kbeg;
   const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
-  int rot = (p.kbeg == 0) ? (mt + 1) * (TILE / KC) : 0;           // first chunk of the rotated k order
-  if (rot >= nc) rot = 0;
   double r[4][NRB];
 #pragma unroll
   for (int am = 0; am < 4; ++am)
@@ -627,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
     const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;
     Acc acc;
     acc.zero();
-    int kc = rot;
+    int kc = 0;
     tile_dma<K_CONTIG>(lds[0][0], Ab + (long)kc * KC, p.ld, wave, lane);
     tile_dma<FREE_CONTIG>(lds[0][1], Bb + (long)kc * KC * p.Mp, p.Mp, wave, lane);
     dma_wait();
@@ -635,7 +638,7 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
     for (int c = 0; c < nc; ++c) {
       const int cur = c & 1;
       if (c + 1 < nc) {
-        kc = (kc + 1 == nc) ? 0 : kc + 1;
+        ++kc;
         int ld_ = lane;
         asm volatile("" : "+v"(ld_));                             // DMA addressing recomputed per chunk instead of held in registers
         tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)kc * KC, p.ld, wave, ld_);
@@ -645,9 +648,7 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
       dma_wait();
       __syncthreads();
     }
-    mfma_drain(acc.v[3][15]);
-#pragma unroll
-    for (int ar = 0; ar < 4; ++ar) acc_fence16(acc.v[ar]);
+    acc.drain();
     // ---- epilogue: all staging buffers are free now.  Its addressing comes from an OPAQUE copy of the lane id so that
     // none of it stays live across the k-loop (as loop invariants these values were spilled to scratch).
     int le = tid;
@@ -700,6 +701,8 @@ __global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
       }
     }
     mfma_drain(r[3][NRB - 1]);
+#pragma unroll
+    for (int am = 0; am < 4; ++am) acc_fence<NRB>(r[am]);
     __syncthreads();   // slabs / xa_s live in the staging buffers the next tile's DMA overwrites
   }
   const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4), lj = lane & 3;
@@ -742,16 +745,13 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
   const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
   const int nc = p.kend - p.kbeg;
   const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
-  int rot = (p.kbeg == 0) ? (mt + 1) * (TILE / KC) : 0;
-  if (rot >= nc) rot = 0;
+  const unsigned lds_base = lds_byte_addr(lds);
   double* const setA = lds + 4608 + wave * 512;
   double* const setB = lds + wave * 512;
   double* const xa_s = lds + 4608 + 4096;
-  double r[2][NRB];
+  double r[2][NRB], gq[NRB];
 #pragma unroll
-  for (int am = 0; am < 2; ++am)
-#pragma unroll
-    for (int g = 0; g < NRB; ++g) r[am][g] = 0.0;
+  for (int g = 0; g < NRB; ++g) { r[0][g] = 0.0; r[1][g] = 0.0; gq[g] = 0.0; }
   // chunk staging: 16 DMA instructions per operand tile, two per wave; lane offsets are 32-bit (uniform base + offset addressing)
   auto chunk_dma = [&](double* buf, const double* a, const double* b) {
     int ld_ = lane;
@@ -760,7 +760,9 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
     for (int i = 0; i < 2; ++i) {
       const int I = wave * 2 + i;
       const int row = swap03(I * 8 + (ld_ >> 3));
-      glds16(a + (unsigned)(row * (int)p.ld + 2 * ((ld_ & 7) ^ (row & 7))), buf + I * 8 * KC);
+      // byte offset as an unsigned 32-bit value: uniform base + 32-bit lane offset addressing (one address register instead of two)
+      glds16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(a) + (unsigned)(8 * (row * (int)p.ld + 2 * ((ld_ & 7) ^ (row & 7))))),
+             buf + I * 8 * KC);
       glds16(b + (long)I * p.Mp + 2u * ld_, buf + TILE_LDS_DOUBLES + I * LDS_RC);
     }
   };
@@ -786,7 +788,8 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
   auto slab_dma = [&](const Epi& e, const double* Ktile, int ar, double* slab) {   // Ktile: row 0, column 0 of the wave's Psi1 block
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      glds16(Ktile + (unsigned)((16 * ar + 4 * i + e.lk) * (int)p.ld + 2 * (e.dpair ^ (2 * i))), slab + i * 128);
+      glds16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Ktile) +
+                                             (unsigned)(8 * ((16 * ar + 4 * i + e.lk) * (int)p.ld + 2 * (e.dpair ^ (2 * i))))), slab + i * 128);
   };
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
@@ -797,7 +800,7 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
     for (int ar = 0; ar < 4; ++ar)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[ar][j] = 0.0;
-    int kc = rot;
+    int kc = 0;
     const int b0 = (nc + 1) & 1;                                // buffer of chunk 0; chunk c uses (c + nc + 1) & 1, the last one buf0
     chunk_dma(lds + b0 * 4608, Ab + (long)kc * KC, Bb + (long)kc * KC * p.Mp);
     dma_wait();
@@ -805,7 +808,7 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
     for (int c = 0; c < nc; ++c) {
       const int cur = (c + nc + 1) & 1;
       if (c + 1 < nc) {
-        kc = (kc + 1 == nc) ? 0 : kc + 1;
+        ++kc;
         chunk_dma(lds + (cur ^ 1) * 4608, Ab + (long)kc * KC, Bb + (long)kc * KC * p.Mp);
       } else {
         // last chunk (computing from buf0): slab 0 of this wave and the tile's Xa rows into buf1 + extra
@@ -817,20 +820,22 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
           glds16(p.Xa + (n0 + row) * p.CXp + 2 * c2, xa_s + I * 128);
         }
       }
-      const double* sA = lds + cur * 4608;
-      const double* sB = sA + TILE_LDS_DOUBLES;
-#pragma unroll
-      for (int k4 = 0; k4 < KC / 4; ++k4) {
+      // operand reads as explicit ds_read_b64 (see mma_f64.h): 4 A + 8 B per k-step, MFMAs start as soon as A and the first B landed
+      const unsigned sbase_b = lds_base + (unsigned)cur * (4608u * 8u);
+      const unsigned aB = sbase_b + TILE_LDS_DOUBLES * 8 + 8u * (unsigned)ofs.b[0];
+      static_for<0, KC / 4>([&](auto k4c) {
+        constexpr int k4 = decltype(k4c)::value;
+        const unsigned aA = sbase_b + 8u * (unsigned)ofs.a[k4];
         double a[4], b[8];
+        a[0] = ds_read64<0>(aA); a[1] = ds_read64<2048>(aA); a[2] = ds_read64<4096>(aA); a[3] = ds_read64<6144>(aA);
+        static_for<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<k4 * 4 * LDS_RC * 8 + 32 * j>(aB); });
+        static_for<0, 8>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          lgkm_wait<7 - j>();
 #pragma unroll
-        for (int ar = 0; ar < 4; ++ar) a[ar] = sA[ofs.a[k4] + 256 * ar];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = sB[ofs.b[0] + 4 * k4 * LDS_RC + 4 * j];
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) mfma444_acc(acc[ar][j], a[ar], b[j]);
-      }
+          for (int ar = 0; ar < 4; ++ar) mfma444_acc(acc[ar][j], a[ar], b[j]);
+        });
+      });
       dma_wait();
       __syncthreads();
     }
@@ -840,7 +845,6 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
     mfma_drain(acc[3][7]);
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);
-    double hsum[4];
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) {
       double* slab = (ar & 1) ? setB : setA;
@@ -854,7 +858,14 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
         slab[idx] = w;
         hs += w;
       }
-      hsum[ar] = quad_sum(hs);     // stored after the last slab: a store in between would blur the vmcnt accounting of the DMAs
+      // grad_alpha's mu^2 term: -1/2 sum_n h_n mu_nq^2 with h_n = this wave's row sum of W; lane (row, lj) takes q = lj + 4 i
+      // (column Q of Xa is the constant 1 and the padding is 0: those accumulators are never read)
+      hs = -0.5 * quad_sum(hs);
+#pragma unroll
+      for (int i = 0; i < NRB; ++i) {
+        const double x = xa_s[(wrow0 + 16 * ar + e.srow) * XS + 4 * i + e.lj];
+        gq[i] = fma(hs * x, x, gq[i]);
+      }
       const double* xrow = xa_s + (wrow0 + 16 * ar + e.lk) * XS + e.lj;
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
@@ -875,12 +886,8 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
         slab_dma(e, Ktile, ar + 2, slab);
       }
     }
-    if (e.lj == 0) {
-      double* hout = p.HZp + (long)(mt * 4 + wc * 2 + half) * p.Np + n0 + wrow0 + e.srow;
-#pragma unroll
-      for (int ar = 0; ar < 4; ++ar) hout[16 * ar] = hsum[ar];
-    }
     mfma_drain(r[1][NRB - 1]);
+    acc_fence<NRB>(r[0]); acc_fence<NRB>(r[1]);
     __syncthreads();   // slabs / xa_s live in the staging buffers the next tile's DMA overwrites
   }
   double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * XS;
@@ -888,6 +895,13 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
   for (int am = 0; am < 2; ++am)
 #pragma unroll
     for (int g = 0; g < NRB; ++g) Rmine[(long)(16 * am + srow) * XS + 4 * g + lj] = (t1 > t0) ? r[am][g] : 0.0;
+  // per-wave partial of the mu^2 term: fixed butterfly over the 16 rows (lane bits 2..5), one row of gapart per wave
+#pragma unroll
+  for (int g = 0; g < NRB; ++g) {
+    double v = gq[g];
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    if (lane < 4) p.gapart[((long)blockIdx.x * 8 + wave) * XS + 4 * g + lane] = v;
+  }
 }
 
 // grad_alpha's mu^2 term from the row sums: out[block][q] = -1/2 sum_{n in block} (sum_p H[p][n]) mu_nq^2   (fixed tree)
@@ -973,12 +987,13 @@ __global__ void __launch_bounds__(256) point_kernel(PtArgs a) {
   }
 }
 
-__global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, const double* __restrict__ b, int rows_b, int Q, double* __restrict__ out) {
+__global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, int lda, const double* __restrict__ b, int rows_b, int ldb, int Q,
+                               double* __restrict__ out) {
   const int q = blockIdx.x;
   __shared__ double red[256];
   double s = 0.0;
-  for (int r = threadIdx.x; r < rows_a; r += 256) s += a[(long)r * Q + q];
-  if (b) for (int r = threadIdx.x; r < rows_b; r += 256) s += b[(long)r * Q + q];
+  for (int r = threadIdx.x; r < rows_a; r += 256) s += a[(long)r * lda + q];
+  if (b) for (int r = threadIdx.x; r < rows_b; r += 256) s += b[(long)r * ldb + q];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
@@ -1006,8 +1021,9 @@ int run_phase2(gp_ctx* c) {
   int hparts = 0;                                    // row-sum partial arrays the fast kernels leave in HZp
   (void)hipEventRecord(c->ev[12], c->stream);
   if (ppath) hipLaunchKernelGGL((p2_kernel<true>), dim3(blocks), dim3(256), 0, c->stream, p);
-  else if (nrb <= 3 && c->p2_variant != 4) {
-    hparts = 4 * p.MT;
+  else if (nrb <= 3) {
+    p.gapart = c->hgpart;
+    GP_HIP(c, hipMemsetAsync(c->hgpart, 0, (size_t)blocks * 8 * 4 * nrb * sizeof(double), c->stream));   // blocks past the last slice exit early
     switch (nrb) {
       case 1: hipLaunchKernelGGL((p2_fast8_kernel<1>), dim3(blocks), dim3(512), 0, c->stream, p); break;
       case 2: hipLaunchKernelGGL((p2_fast8_kernel<2>), dim3(blocks), dim3(512), 0, c->stream, p); break;
@@ -1038,12 +1054,15 @@ int run_phase2(gp_ctx* c) {
     a.gmu = c->gXmu; a.gS = c->gXs; a.gapart = c->gapart; a.regimeA = c->regime_A ? 1 : 0;
     hipLaunchKernelGGL(point_kernel, dim3(c->ga_blocks), dim3(256), 256 * sizeof(double), c->stream, a);
     GP_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->gapart, c->ga_blocks, c->Q, ga);
+    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, c->gapart, c->ga_blocks, c->Q, c->Q, ga);
   } else {
-    const int hb = (int)((c->N + 255) / 256);        // <= ga_blocks' allocation? gapart holds ga_blocks*Q; use klpart-sized buffer instead
-    hipLaunchKernelGGL(p2_ga_kernel, dim3(hb), dim3(256), 0, c->stream, c->HZp, hparts, (long)c->N, (long)c->Np, c->Q, c->mu, c->hgpart);
-    GP_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->hgpart, hb, c->Q, ga);
+    int hb = blocks * 8, hstride = 4 * nrb;          // eight-wave kernel: one partial row per wave
+    if (hparts > 0) {                                // four-wave kernel: row sums in HZp, finished by p2_ga_kernel
+      hb = (int)((c->N + 255) / 256); hstride = c->Q;
+      hipLaunchKernelGGL(p2_ga_kernel, dim3(hb), dim3(256), 0, c->stream, c->HZp, hparts, (long)c->N, (long)c->Np, c->Q, c->mu, c->hgpart);
+      GP_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, c->hgpart, hb, hstride, c->Q, ga);
   }
   GP_HIP(c, hipGetLastError());
   return GP_OK;

@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgparml_hip.so')
 
-GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_ERR_HIP, GP_ERR_STATE, GP_ERR_UNSUPPORTED = range(7)
+GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_ERR_HIP, GP_ERR_STATE, GP_ERR_UNSUPPORTED, GP_RETRY_JITTER = range(8)
 
 # gp_download selectors (include/gparml_hip.h)
 ARR = dict(KMM=0, KMM_INV=1, PSI1=2, PSI2_SUM=3, PSI1TY=4, KMM_PLUS_OP_INV=5, DF_DKMM=6, DF_DPSI1TY=7, DF_DPSI2=8,
@@ -34,8 +34,12 @@ SIGNATURES = {
     'gp_phase1': (ctypes.c_int, [_vp]),
     'gp_stats_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     'gp_scale_stats': (ctypes.c_int, [_vp, ctypes.c_double]),
+    'gp_scale_buffer': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
+    'gp_debug_force_staging': (ctypes.c_int, [ctypes.c_int]),
     'gp_buffer_combine': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
     'gp_global_step': (ctypes.c_int, [_vp]),
+    'gp_global_step_jitter': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'gp_global_status': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     'gp_phase2': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gp_grads_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     'gp_finish': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
@@ -57,6 +61,15 @@ _lib = None
 
 class GparmlHipError(RuntimeError):
     pass
+
+
+class JitterRetry(Exception):
+    """A Cholesky factorisation of the global step failed for the first time: repeat it with 1e-7*I on the matrices in
+    ``mask`` (bit 0 Kmm, bit 1 Kmm + beta*Psi2), as partial_terms.logmarglik does (partial_terms.py:452-456)."""
+
+    def __init__(self, mask, msg=''):
+        Exception.__init__(self, msg)
+        self.mask = int(mask)
 
 
 def load():

@@ -140,7 +140,8 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   A(&c->dFdK, (size_t)Mp * Mp); A(&c->Bbar, (size_t)Mp * Mp);
   A(&c->E, (size_t)Mp * Dp); A(&c->PsiE, (size_t)Mp * Dp); A(&c->Abar, (size_t)Mp * Dp);
   A(&c->Bm, (size_t)c->LDK * Mp);
-  A(&c->gs, (size_t)GS_COUNT + 8); A(&c->gK, (size_t)M * Q + Q);
+  A(&c->gs, (size_t)GS_COUNT + 8 + 8 * 64);   // scalars | failure flags | dots_kernel partials [8 jobs][64 blocks]
+  A(&c->gK, (size_t)M * Q + Q);
   // phase 2
   c->p2_slices = std::max(1, std::min<int>(8 * std::max(1, 64 / mt), (int)(Np / TILE)));
   A(&c->Rpart, (size_t)2 * (c->p2_slices + 8) * Mp * c->CXp);
@@ -172,6 +173,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (c->ptiles) (void)hipFree(c->ptiles);
   if (c->tiles64) (void)hipFree(c->tiles64);
   if (c->bmap) (void)hipFree(c->bmap);
+  if (c->staging) (void)hipFree(c->staging);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return GP_OK;
@@ -329,40 +331,75 @@ __global__ void grad_latest_kernel(const double* __restrict__ gmu, const double*
   }
 }
 
+static bool g_force_staging = false;   // test hook: take the cross-device path of gp_buffer_combine on one device
+extern "C" int gp_debug_force_staging(int on) { g_force_staging = on != 0; return GP_OK; }
+
 extern "C" int gp_buffer_combine(gp_ctx* dst, const gp_ctx* src, int which, int op) {
   if (!dst || !src) return GP_ERR_BAD_ARG;
-  if (dst->device != src->device) return fail(dst, GP_ERR_BAD_ARG, "gp_buffer_combine: contexts on different devices");
   if (dst->M != src->M || dst->Q != src->Q || dst->D != src->D) return fail(dst, GP_ERR_BAD_ARG, "gp_buffer_combine: shape mismatch");
-  GP_HIP(dst, hipSetDevice(dst->device));
   const long n = which == 0 ? (long)dst->Mp * dst->Mp + (long)dst->Mp * dst->Dp + SC_COUNT : (long)dst->M * dst->Q + dst->Q;
-  if (src->stream != dst->stream) GP_HIP(dst, hipStreamSynchronize(src->stream));
-  hipLaunchKernelGGL(combine_kernel, dim3(blocks_for(n)), dim3(256), 0, dst->stream, which == 0 ? dst->stats : dst->grads,
-                     which == 0 ? src->stats : src->grads, n, op);
+  const double* from = which == 0 ? src->stats : src->grads;
+  // the source context's work must have finished before its buffer is read from another stream / device
+  if (src->stream != dst->stream || src->device != dst->device) {
+    GP_HIP(dst, hipSetDevice(src->device));
+    GP_HIP(dst, hipStreamSynchronize(src->stream));
+  }
+  GP_HIP(dst, hipSetDevice(dst->device));
+  if (src->device != dst->device || g_force_staging) {
+    // shards on different GPUs of one process (options['devices']): peer copy into a staging buffer on the destination
+    // device, then the same combine kernel -- the device-side form of statistics_reducer (local_MapReduce.py:250-277)
+    if (dst->staging_doubles < (size_t)n) {
+      if (dst->staging) (void)hipFree(dst->staging);
+      dst->staging = nullptr; dst->staging_doubles = 0;
+      GP_HIP(dst, hipMalloc((void**)&dst->staging, (size_t)n * 8));
+      dst->staging_doubles = (size_t)n;
+    }
+    GP_HIP(dst, hipMemcpyPeerAsync(dst->staging, dst->device, from, src->device, (size_t)n * 8, dst->stream));
+    from = dst->staging;
+  }
+  hipLaunchKernelGGL(combine_kernel, dim3(blocks_for(n)), dim3(256), 0, dst->stream, which == 0 ? dst->stats : dst->grads, from, n, op);
   GP_HIP(dst, hipGetLastError());
   if (which == 0 && dst->state < 1) dst->state = 1;
   return GP_OK;
 }
 
-extern "C" int gp_scale_stats(gp_ctx* c, double f) {
+extern "C" int gp_scale_buffer(gp_ctx* c, int which, double f) {
   if (!c) return GP_ERR_BAD_ARG;
-  if (c->state < 1) return fail(c, GP_ERR_STATE, "gp_scale_stats before gp_phase1");
+  if (which != 0 && which != 1) return fail(c, GP_ERR_BAD_ARG, "gp_scale_buffer: which must be 0 (statistics) or 1 (gradient sums)");
+  if (which == 0 && c->state < 1) return fail(c, GP_ERR_STATE, "gp_scale_buffer(statistics) before gp_phase1");
+  if (which == 1 && c->state < 3) return fail(c, GP_ERR_STATE, "gp_scale_buffer(gradient sums) before gp_phase2");
   GP_HIP(c, hipSetDevice(c->device));
-  const long n = (long)c->Mp * c->Mp + (long)c->Mp * c->Dp + SC_COUNT;
-  hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->stats, n, f);
+  const long n = which == 0 ? (long)c->Mp * c->Mp + (long)c->Mp * c->Dp + SC_COUNT : (long)c->M * c->Q + c->Q;
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, which == 0 ? c->stats : c->grads, n, f);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }
 
-extern "C" int gp_global_step(gp_ctx* c) {
+extern "C" int gp_scale_stats(gp_ctx* c, double f) { return gp_scale_buffer(c, 0, f); }
+
+extern "C" int gp_global_step_jitter(gp_ctx* c, int jitter_mask) {
   if (!c) return GP_ERR_BAD_ARG;
   if (c->state < 1) return fail(c, GP_ERR_STATE, "gp_global_step before gp_phase1 / gp_set_local_statistics");
+  if (jitter_mask < 0 || jitter_mask > 3) return fail(c, GP_ERR_BAD_ARG, "gp_global_step_jitter: mask must be 0..3");
   GP_HIP(c, hipSetDevice(c->device));
+  c->jitter_mask = jitter_mask;
   GP_HIP(c, hipEventRecord(c->ev[3], c->stream));
   const int rc_gs = run_global_step(c);
   GP_HIP(c, hipEventRecord(c->ev[4], c->stream));
   if (rc_gs != GP_OK) return rc_gs;
   c->state = 2;
   return GP_OK;
+}
+
+extern "C" int gp_global_step(gp_ctx* c) { return gp_global_step_jitter(c, 0); }
+
+extern "C" int gp_global_status(gp_ctx* c, int* retry_mask) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_global_status before gp_global_step");
+  GP_HIP(c, hipSetDevice(c->device));
+  const int rc = check_global(c);
+  if (retry_mask) *retry_mask = (rc == GP_RETRY_JITTER) ? c->retry_mask : 0;
+  return rc;
 }
 
 extern "C" int gp_phase2(gp_ctx* c, int want_embedding_grads) {
@@ -413,6 +450,9 @@ extern "C" int gp_download(gp_ctx* c, int which, double* dst, int64_t n) {
   if (!c || !dst) return GP_ERR_BAD_ARG;
   GP_HIP(c, hipSetDevice(c->device));
   const long M = c->M, Mp = c->Mp, D = c->D, Dp = c->Dp, N = c->N, Q = c->Q;
+  if (c->state >= 2 && (which == GP_ARR_KMM_INV || which == GP_ARR_KMM_PLUS_OP_INV || which == GP_ARR_DF_DKMM || which == GP_ARR_DF_DPSI1TY ||
+                        which == GP_ARR_DF_DPSI2 || which == GP_ARR_SCALARS))
+    GP_TRY(check_global(c));
   switch (which) {
     case GP_ARR_PSI1: return download_matrix(c, c->Kaug, c->LDK, N, M, dst, n);
     case GP_ARR_PSI2_SUM: return download_matrix(c, c->stats, Mp, M, M, dst, n);
@@ -497,6 +537,7 @@ extern "C" int gp_finish(gp_ctx* c, double* F, double* grad_Z, double* grad_sf2,
   if (!c) return GP_ERR_BAD_ARG;
   if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_finish before gp_global_step");
   GP_HIP(c, hipSetDevice(c->device));
+  GP_TRY(check_global(c));   // the one host synchronisation of an evaluation: scalars + failure flags of the global step
   if (F) *F = c->h_gs[GS_F];
   if (grad_sf2) *grad_sf2 = c->h_gs[GS_GRAD_SF2];
   if (grad_beta) *grad_beta = c->h_gs[GS_GRAD_BETA];

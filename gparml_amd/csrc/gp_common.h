@@ -76,6 +76,8 @@ struct gp_ctx {
   bool stats_external = false;
   double* grads = nullptr;    // packed: gZ_data [M*Q] | galpha_data [Q]
   bool grads_external = false;
+  double* staging = nullptr;  // landing buffer for a peer copy from a shard on another device (gp_buffer_combine)
+  size_t staging_doubles = 0;
   double* part = nullptr;     // phase-1 split-k partials
   size_t part_doubles = 0;
   int* tiles = nullptr;       // phase-1 tile table (int2)
@@ -102,6 +104,11 @@ struct gp_ctx {
   double* gs = nullptr;       // [GS_COUNT] device scalars
   double* gK = nullptr;       // [M*Q + Q] Kmm-parts of grad_Z / grad_alpha (+ regime-B alpha term)
   double h_gs[gp::GS_COUNT] = {0};
+  bool gs_pending = false;    // a global step was enqueued and its scalars / failure flags have not been read back yet
+  int gs_status = 0;          // outcome of the last global step once read back (GP_OK, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_RETRY_JITTER)
+  std::string gs_msg;
+  int jitter_mask = 0;        // bit 0: Kmm, bit 1: Kmm + beta*Psi2 get 1e-7 * I in this global step (partial_terms.py:452-456)
+  int retry_mask = 0;         // what a GP_RETRY_JITTER asks the caller to pass to gp_global_step_jitter
   // phase 2
   double* Rpart = nullptr;    // [p2_slices][Mp][CXp]
   int p2_slices = 0;
@@ -165,6 +172,7 @@ int run_dz2(gp_ctx* c);
 int compat_build(gp_ctx* c, int which, double** out, long* count);
 // linalg.hip
 int run_global_step(gp_ctx* c);
+int check_global(gp_ctx* c);
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,
                           double* Twork /*[batch][128][Mp]*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/,
                           double* splitk_ws /*may be NULL*/);

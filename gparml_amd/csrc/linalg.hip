@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(1024) potrf_diag_kernel(double* A, long ld, lo
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[r][c] = (ti >= tj) ? blk[(long)(4 * ti + r) * ld + 4 * tj + c] : 0.0;
-  bool bad = false;
+  double bad = 0.0;   // 1: negative (or NaN) pivot -- indefinite; 2: pivot exactly zero -- singular (numpy.linalg.inv raises for that one)
   for (int bj = 0; bj < 32; ++bj) {
     double (*panel)[5] = panel2[bj & 1];
     if (ti == bj && tj == bj) {
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(1024) potrf_diag_kernel(double* A, long ld, lo
         double d2 = a[c][c];
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (k < c) d2 -= a[c][k] * a[c][k];
-        if (!(d2 > 0.0) || !(d2 < 1e300)) { bad = true; d2 = 1.0; }
+        if (!(d2 > 0.0) || !(d2 < 1e300)) { bad = fmax(bad, d2 == 0.0 ? 2.0 : 1.0); d2 = 1.0; }
         const double d = sqrt(d2);
         inv[c] = 1.0 / d;
         a[c][c] = d;
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(1024) potrf_diag_kernel(double* A, long ld, lo
           Lbb[r][c] = (c == r) ? inv[c] : v;      // diagonal slot holds 1 / L_cc
           panel[4 * ti + r][c] = v;
         }
-      if (bad) fail[blockIdx.x] = 1.0;
+      if (bad != 0.0) fail[blockIdx.x] = fmax(fail[blockIdx.x], bad);
     }
     __syncthreads();
     if (tj == bj && ti > bj) {
@@ -225,9 +225,11 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
 
 // ---------------------------------------------------------------------------------------------- global step kernels
 // Kmm (kernels.py:108-111) and A = Kmm + beta * Psi2, identity in the padded block
+// jitK / jitA: the 1e-7 * I the reference adds when a determinant sign is negative (partial_terms.py:452-456); 0 on the first attempt
 __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict__ Z, const double* __restrict__ alpha, double sf2,
                                                          double beta, const double* __restrict__ Psi2, int M, int Mp, int Q,
-                                                         double* __restrict__ Kmm, double* __restrict__ A, double* __restrict__ Keep) {
+                                                         double* __restrict__ Kmm, double* __restrict__ A, double* __restrict__ Keep,
+                                                         double jitK, double jitA) {
   const long total = (long)Mp * Mp;
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
     const int i = (int)(idx / Mp), k = (int)(idx - (long)i * Mp);
@@ -242,17 +244,20 @@ __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict
     } else {
       v = (i == k) ? 1.0 : 0.0;
     }
-    Kmm[idx] = v;
+    const bool diag = (i == k) && i < M;
+    Kmm[idx] = v + (diag ? jitK : 0.0);
     Keep[idx] = v;
-    A[idx] = v + ((i < M && k < M) ? beta * Psi2[idx] : 0.0);
+    A[idx] = v + ((i < M && k < M) ? beta * Psi2[idx] : 0.0) + (diag ? jitA : 0.0);
   }
 }
 
 // sum over the M x M (or M x D) block of x o y; one block per pair, results into out[slot]
 struct DotJob { const double* x; const double* y; long ld; int rows, cols; int slot; };
 struct DotJobs { DotJob j[8]; int n; };
-__global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* out) {
-  // grid (64, jobs): 64 blocks per job, atomically combined (out is zeroed by the caller)
+constexpr int DOT_BLOCKS = 64;
+__global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* part) {
+  // grid (DOT_BLOCKS, jobs): per-block partial sums part[job][block]; scalars_kernel adds them in a fixed order, so the bound is
+  // bit-identical from run to run (an atomicAdd here made the last bits of F depend on the block schedule)
   __shared__ double red[256];
   const DotJob jb = jobs.j[blockIdx.y];
   double s = 0.0;
@@ -264,7 +269,7 @@ __global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* out) {
     if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(&out[jb.slot], red[0]);
+  if (threadIdx.x == 0) part[blockIdx.y * DOT_BLOCKS + blockIdx.x] = red[0];
 }
 
 // Bbar, dF/dKmm, Abar and the phase-2 operand Bm = [2 Bbar ; Abar^T]
@@ -292,8 +297,15 @@ __global__ void __launch_bounds__(256) assemble_kernel(const double* __restrict_
 }
 
 // F, grad_beta, grad_sf2 from the traces (partial_terms.py:464-472, 346-358, 322-333)
-__global__ void scalars_kernel(const double* sc, double* gs, double beta, double sf2, double Dd, double Nglob) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void scalars_kernel(const double* sc, double* gs, DotJobs jobs, const double* part, double beta, double sf2, double Dd, double Nglob) {
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x < jobs.n) {
+    double s = 0.0;
+    for (int b = 0; b < DOT_BLOCKS; ++b) s += part[threadIdx.x * DOT_BLOCKS + b];
+    gs[jobs.j[threadIdx.x].slot] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const double sumYY = sc[SC_SUM_YYT], Psi0 = sc[SC_PSI0], KL = sc[SC_KL];
   const double ldK = gs[GS_LOGDET_K], ldA = gs[GS_LOGDET_A];
   const double trKi = gs[GS_TR_KIPSI2], trP = gs[GS_TR_PPSI2], trCE = gs[GS_TR_CE], trEPE = gs[GS_TR_EPSI2E];
@@ -349,6 +361,40 @@ __global__ void __launch_bounds__(256) colsum_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) out[q] = red[0];
 }
 
+// Host side of the global step's outcome: one D2H of the scalars + failure flags, at the first call that needs them
+// (gp_global_status, gp_finish, gp_download).  Returns GP_OK, GP_ERR_NOT_PD, GP_ERR_NON_FINITE or GP_RETRY_JITTER.
+int check_global(gp_ctx* c) {
+  if (c->gs_pending) {
+    double h[GS_COUNT + 8];
+    GP_HIP(c, hipMemcpyAsync(h, c->gs, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < GS_COUNT; ++i) c->h_gs[i] = h[i];
+    c->gs_pending = false;
+    const int failed = (h[GS_COUNT] != 0.0 ? 1 : 0) | (h[GS_COUNT + 1] != 0.0 ? 2 : 0);
+    const bool singular = h[GS_COUNT] == 2.0 || h[GS_COUNT + 1] == 2.0;
+    if (singular) {
+      // an exactly zero pivot: the reference fails in linalg.inv before any jitter applies (partial_terms.py:60, 95)
+      c->gs_status = GP_ERR_NOT_PD;
+      c->gs_msg = std::string(h[GS_COUNT] == 2.0 ? "Kmm" : "Kmm + beta*Psi2") + " is singular (numpy.linalg.inv: Singular matrix)";
+    } else if (failed & ~c->jitter_mask) {
+      // first failure of this matrix: the reference continues with 1e-7 * I added (partial_terms.py:452-456)
+      c->retry_mask = c->jitter_mask | failed;
+      c->gs_status = GP_RETRY_JITTER;
+      c->gs_msg = std::string(failed & 1 ? "Kmm" : "Kmm + beta*Psi2") + " is not positive definite (Cholesky failed); retry with 1e-7 jitter";
+    } else if (failed) {
+      c->gs_status = GP_ERR_NOT_PD;
+      c->gs_msg = std::string(failed & 1 ? "Kmm" : "Kmm + beta*Psi2") + " is not positive definite even with 1e-7 jitter (partial_terms.py:459-461 assertion)";
+    } else if (!std::isfinite(h[GS_F])) {
+      c->gs_status = GP_ERR_NON_FINITE;
+      c->gs_msg = "bound is not finite";
+    } else {
+      c->gs_status = GP_OK;
+    }
+  }
+  if (c->gs_status != GP_OK) return fail(c, c->gs_status, "%s", c->gs_msg.c_str());
+  return GP_OK;
+}
+
 int run_global_step(gp_ctx* c) {
   hipStream_t st = c->stream;
   const int Mp = c->Mp, Dp = c->Dp, M = c->M, D = c->D, Q = c->Q;
@@ -357,9 +403,10 @@ int run_global_step(gp_ctx* c) {
   double* C = c->stats + mm;
   double* sc = c->stats + mm + (long)Mp * Dp;
   GP_HIP(c, hipMemsetAsync(c->gs, 0, (GS_COUNT + 8) * sizeof(double), st));
+  c->gs_status = GP_OK;
   double* failf = c->gs + GS_COUNT;  // [2]
   hipLaunchKernelGGL(build_kmm_kernel, dim3(1024), dim3(256), 0, st, c->Z, c->alpha, c->sf2, c->beta, Psi2, M, Mp, Q, c->Kmm, c->Kmm + mm,
-                     c->KmmKeep);
+                     c->KmmKeep, (c->jitter_mask & 1) ? 1e-7 : 0.0, (c->jitter_mask & 2) ? 1e-7 : 0.0);
   GP_HIP(c, hipGetLastError());
   // factorise [Kmm ; A] in place, invert.  T1 is the 2 x 128 x Mp work panel.
   // split-k workspace: the phase-1 partial buffer is free during the global step (>= 600 tiles)
@@ -397,20 +444,15 @@ int run_global_step(gp_ctx* c) {
   jobs.j[4] = {c->dFdK, c->KmmKeep, Mp, M, M, GS_SUM_V};
   jobs.j[5] = {c->Abar, C, Dp, M, D, GS_SUM_AC};
   jobs.j[6] = {c->Bbar, Psi2, Mp, M, M, GS_SUM_BPSI2};
-  hipLaunchKernelGGL(dots_kernel, dim3(64, jobs.n), dim3(256), 0, st, jobs, c->gs);
-  hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, c->beta, c->sf2, (double)D, (double)c->N_global);
+  double* dpart = c->gs + GS_COUNT + 8;   // [jobs][DOT_BLOCKS]
+  hipLaunchKernelGGL(dots_kernel, dim3(DOT_BLOCKS, jobs.n), dim3(256), 0, st, jobs, dpart);
+  hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, jobs, dpart, c->beta, c->sf2, (double)D, (double)c->N_global);
   // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
   hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, st, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
                      c->regime_A ? 1 : 0, c->gK, c->T2);
   hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, st, c->T2, M, Q, c->gK + (long)M * Q);
   GP_HIP(c, hipGetLastError());
-  double h[GS_COUNT + 8];
-  GP_HIP(c, hipMemcpyAsync(h, c->gs, sizeof(h), hipMemcpyDeviceToHost, st));
-  GP_HIP(c, hipStreamSynchronize(st));
-  for (int i = 0; i < GS_COUNT; ++i) c->h_gs[i] = h[i];
-  if (h[GS_COUNT] != 0.0) return fail(c, GP_ERR_NOT_PD, "Kmm is not positive definite (Cholesky failed)");
-  if (h[GS_COUNT + 1] != 0.0) return fail(c, GP_ERR_NOT_PD, "Kmm + beta*Psi2 is not positive definite (Cholesky failed)");
-  if (!std::isfinite(h[GS_F])) return fail(c, GP_ERR_NON_FINITE, "bound is not finite");
+  c->gs_pending = true;   // scalars and failure flags are read back at the next host synchronisation point (check_global)
   return GP_OK;
 }
 

@@ -10,6 +10,8 @@ oracle-backed stand-in while the product path uses gparml_amd.engine.ShardEngine
 """
 import numpy as np
 
+from ._lib import JitterRetry
+
 
 class _DevArray(object):
     """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface v2)."""
@@ -51,18 +53,57 @@ class DistributedEvaluator(object):
                 self._grads_t = device_tensor(p, n, self.device)
         return self._stats_t, self._grads_t
 
-    def evaluate(self, want_embedding_grads=False, kept_fraction=None):
-        """One bound+gradient evaluation across all shards.  ``kept_fraction`` reproduces the node drop-out
-        rescale of local_MapReduce.py:263-264 (statistics divided by kept/(kept+dropped))."""
+    def evaluate(self, want_embedding_grads=False, kept_mask=None, kept_fraction=None):
+        """One bound+gradient evaluation across all shards.
+
+        Node drop-out (local_MapReduce.py:119-129, 263-264): ``kept_mask`` is the keep/drop decision for EVERY rank, identical on all
+        ranks (``draw_kept_mask`` with a shared seed).  A dropped rank contributes nothing to either reduction -- the reference
+        sums all twelve statistics, the derivative sums behind grad_Z / grad_alpha included, over the kept nodes only -- and both
+        reduced buffers are divided by ``kept_fraction`` = kept/(kept+dropped).  Every rank still runs phase 2 for its own embedding
+        gradients (embeddings_MR visits all nodes, local_MapReduce.py:293-295)."""
         eng = self.engine
-        stats_t, grads_t = self._tensors()
+        collective = self.world > 1 or self.force
+        stats_t, grads_t = self._tensors() if collective else (None, None)   # zero-copy torch views of the packed device buffers
+        kept_here = True
+        if kept_mask is not None:
+            kept_mask = [bool(k) for k in kept_mask]
+            assert len(kept_mask) == self.world, 'kept_mask needs one entry per rank'
+            kept_here = kept_mask[self.rank]
+            if kept_fraction is None:
+                kept_fraction = float(sum(kept_mask)) / len(kept_mask)
+        rescale = kept_fraction is not None and kept_fraction != 1.0
         eng.phase1()
-        if self.world > 1 or self.force:
+        if not kept_here:
+            eng.scale_buffer('stats', 0.0)
+        if collective:
             self.dist.all_reduce(stats_t, op=self.dist.ReduceOp.SUM, group=self.group)
-        if kept_fraction is not None and kept_fraction != 1.0:
-            eng.scale_stats(1.0 / kept_fraction)
-        eng.global_step()
-        eng.phase2(want_embedding_grads)
-        if self.world > 1 or self.force:
-            self.dist.all_reduce(grads_t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return eng.finish()
+        if rescale:
+            eng.scale_buffer('stats', 1.0 / kept_fraction)
+        jitter = 0
+        while True:
+            eng.global_step(sync=False, jitter=jitter)
+            eng.phase2(want_embedding_grads)
+            if not kept_here:
+                eng.scale_buffer('grads', 0.0)
+            if collective:
+                self.dist.all_reduce(grads_t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if rescale:
+                eng.scale_buffer('grads', 1.0 / kept_fraction)
+            try:
+                return eng.finish()       # the evaluation's only host synchronisation
+            except JitterRetry as r:
+                # every rank holds the same reduced statistics and runs the same replicated global step, so all ranks take this
+                # branch together: repeat the global step with the reference's 1e-7 jitter (partial_terms.py:452-456)
+                jitter = r.mask
+
+
+def draw_kept_mask(n_nodes, drop_out_fraction, rng):
+    """The keep/drop draw of statistics_MR (local_MapReduce.py:119-129) -> (kept_mask, kept_fraction).  When every node is dropped the
+    reference keeps one random node but leaves ALL n nodes in its dropped list, so its divisor is 1/(n+1) (:126-128, 263-264)."""
+    drop = rng.uniform(size=n_nodes) < drop_out_fraction
+    kept = ~drop
+    if not kept.any():
+        kept = np.zeros(n_nodes, dtype=bool)
+        kept[rng.randint(0, n_nodes)] = True
+        return list(kept), 1.0 / (n_nodes + 1)
+    return list(kept), float(kept.sum()) / n_nodes

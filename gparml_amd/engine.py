@@ -123,8 +123,28 @@ class ShardEngine(object):
     def scale_stats(self, factor):
         self._ck(self.lib.gp_scale_stats(self.h, float(factor)), 'gp_scale_stats')
 
-    def global_step(self):
-        self._ck(self.lib.gp_global_step(self.h), 'gp_global_step')
+    def scale_buffer(self, which, factor):
+        """Scale the packed statistics ('stats') or gradient-sum ('grads') buffer: node drop-out, local_MapReduce.py:119-129, 263-264."""
+        self._ck(self.lib.gp_scale_buffer(self.h, 0 if which == 'stats' else 1, float(factor)), 'gp_scale_buffer')
+
+    def global_step(self, sync=True, jitter=0):
+        """Enqueue the global step.  ``sync=True`` (the class / MapReduce surfaces) also waits for its outcome, repeats it once with the
+        reference's 1e-7 jitter when a factorisation failed (partial_terms.py:452-456) and raises LinAlgError if that fails too;
+        ``sync=False`` (the evaluators) defers all of that to finish(), the evaluation's single host synchronisation."""
+        self._ck(self.lib.gp_global_step_jitter(self.h, int(jitter)), 'gp_global_step')
+        if sync:
+            try:
+                self.global_status()
+            except _lib.JitterRetry as r:
+                self._ck(self.lib.gp_global_step_jitter(self.h, r.mask), 'gp_global_step')
+                self.global_status()
+
+    def global_status(self):
+        mask = ctypes.c_int(0)
+        rc = self.lib.gp_global_status(self.h, ctypes.byref(mask))
+        if rc == _lib.GP_RETRY_JITTER:
+            raise _lib.JitterRetry(mask.value, 'gp_global_status: retry with jitter mask %d' % mask.value)
+        self._ck(rc, 'gp_global_status')
 
     def phase2(self, want_embedding_grads=False):
         self._ck(self.lib.gp_phase2(self.h, 1 if want_embedding_grads else 0), 'gp_phase2')
@@ -135,16 +155,24 @@ class ShardEngine(object):
         gb = ctypes.c_double()
         gZ = np.empty((self.M, self.Q))
         ga = np.empty(self.Q)
-        self._ck(self.lib.gp_finish(self.h, ctypes.byref(F), gZ.ctypes.data_as(_lib._dp), ctypes.byref(gs),
-                                    ga.ctypes.data_as(_lib._dp), ctypes.byref(gb)), 'gp_finish')
+        rc = self.lib.gp_finish(self.h, ctypes.byref(F), gZ.ctypes.data_as(_lib._dp), ctypes.byref(gs),
+                                ga.ctypes.data_as(_lib._dp), ctypes.byref(gb))
+        if rc == _lib.GP_RETRY_JITTER:
+            self.global_status()        # raises JitterRetry carrying the mask
+        self._ck(rc, 'gp_finish')
         return dict(F=F.value, grad_Z=gZ, grad_sf2=gs.value, grad_alpha=ga, grad_beta=gb.value)
 
     def evaluate(self, want_embedding_grads=False):
-        """Single-shard evaluation (no reduction across shards)."""
+        """Single-shard evaluation (no reduction across shards); one host synchronisation, in finish()."""
         self.phase1()
-        self.global_step()
+        self.global_step(sync=False)
         self.phase2(want_embedding_grads)
-        out = self.finish()
+        try:
+            out = self.finish()
+        except _lib.JitterRetry as r:
+            self.global_step(sync=False, jitter=r.mask)
+            self.phase2(want_embedding_grads)
+            out = self.finish()
         if want_embedding_grads:
             out['grad_X_mu'] = self.download('GRAD_X_MU')
             if not self.regime_A_hint:

@@ -38,7 +38,8 @@ enum {
   GP_ERR_NON_FINITE = 3,   /* -> FloatingPointError (nputil.py:9 np.seterr(all='raise'))                    */
   GP_ERR_HIP = 4,          /* -> RuntimeError                                                               */
   GP_ERR_STATE = 5,        /* call sequence violated (e.g. phase2 before global_step) -> RuntimeError       */
-  GP_ERR_UNSUPPORTED = 6
+  GP_ERR_UNSUPPORTED = 6,
+  GP_RETRY_JITTER = 7      /* a Cholesky factorisation failed for the first time: repeat the global step with gp_global_step_jitter */
 };
 
 /* what gp_download can fetch (every array the reference exposes on the path) */
@@ -98,14 +99,30 @@ int gp_phase1(gp_ctx* ctx);
 /* packed device buffer the host all-reduces (sum) across shards: the statistics_reducer
  * (local_MapReduce.py:250-277).  Layout: Psi2 (Mp*Mp) | C (Mp*Dp) | sum_YYT, Psi0, KL, n_local, pad(4) */
 int gp_stats_buffer(gp_ctx* ctx, void** dev_ptr, int64_t* n_doubles);
-/* same-device reduce for several shards in one process (statistics_reducer, local_MapReduce.py:250-277):
- * which=0 statistics buffer, which=1 phase-2 gradient-sum buffer; op=0 dst += src, op=1 dst = src */
+/* device-side reduce for several shards in one process (statistics_reducer, local_MapReduce.py:250-277), on one GPU or
+ * across GPUs (peer copy into a staging buffer of dst): which=0 statistics buffer, which=1 phase-2 gradient-sum buffer;
+ * op=0 dst += src, op=1 dst = src */
 int gp_buffer_combine(gp_ctx* dst, const gp_ctx* src, int which, int op);
-/* scale the reduced statistics (node drop-out rescale, local_MapReduce.py:263-264) */
-int gp_scale_stats(gp_ctx* ctx, double factor);
+/* node drop-out (local_MapReduce.py:119-129, 263-264): the reference sums every statistic over the kept nodes only and divides
+ * by kept/(kept+dropped).  A dropped shard's contribution is excluded by the caller (factor 0 before the reduction), the reduced
+ * buffers are scaled by (kept+dropped)/kept after it: which=0 statistics (before gp_global_step), which=1 gradient sums (after
+ * gp_phase2; they are the contracted form of the reference's sum_d_*_d_Z / d_alpha statistics). */
+int gp_scale_buffer(gp_ctx* ctx, int which, double factor);
+int gp_scale_stats(gp_ctx* ctx, double factor);   /* = gp_scale_buffer(ctx, 0, factor) */
 /* calculate_global_statistics + Kmm parts of calculate_global_derivatives (parallel_GPLVM.py:302-369):
- * Kmm, Cholesky of Kmm and Kmm+beta*Psi2, F, dF_d*, grad_beta.  GP_ERR_NOT_PD if a factorisation fails. */
+ * Kmm, Cholesky of Kmm and Kmm+beta*Psi2, F, dF_d*, grad_beta.  Asynchronous: the launches are enqueued and nothing is
+ * read back; the outcome is reported by the first of gp_global_status / gp_finish / gp_download that follows (one host
+ * synchronisation per evaluation). */
 int gp_global_step(gp_ctx* ctx);
+/* The reference adds 1e-7*I to Kmm (bit 0) and / or Kmm+beta*Psi2 (bit 1) when slogdet reports a negative sign and carries on
+ * (partial_terms.logmarglik, partial_terms.py:452-456); if that does not help it asserts (:459-461).  Here a failed Cholesky is
+ * reported once as GP_RETRY_JITTER (with the mask to use); the caller repeats the global step -- and phase 2 and its reduction --
+ * through this entry.  A second failure of the same matrix is GP_ERR_NOT_PD.  The jittered matrix is used for the log-determinant
+ * AND the inverse (the reference keeps the un-jittered LU inverse of the indefinite matrix for the traces and gradients). */
+int gp_global_step_jitter(gp_ctx* ctx, int jitter_mask);
+/* synchronise and report the outcome of the last global step: GP_OK, GP_RETRY_JITTER (*retry_mask = mask to pass on),
+ * GP_ERR_NOT_PD, GP_ERR_NON_FINITE.  retry_mask may be NULL. */
+int gp_global_status(gp_ctx* ctx, int* retry_mask);
 /* embeddings_mapper body + data-dependent sums of the Z/alpha gradients
  * (local_MapReduce.py:348-358; partial_terms.py:162-205, 256-284, 367-431) */
 int gp_phase2(gp_ctx* ctx, int want_embedding_grads);
@@ -160,6 +177,8 @@ int gp_csv_read(const char* path, double* out, int64_t rows, int64_t cols, int t
  * B (k,n) or (n,k) if tb; any sizes (padded internally) */
 int gp_debug_gemm(int device, int ta, int tb, int m, int n, int k, double alpha, const double* A, const double* B,
                   double beta, double* C);
+/* make gp_buffer_combine take its cross-device path (peer copy through the staging buffer) even on one device */
+int gp_debug_force_staging(int on);
 /* in-place lower Cholesky + inverse of an SPD (n,n) matrix; logdet out; returns GP_ERR_NOT_PD on failure */
 int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet);
 

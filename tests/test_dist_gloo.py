@@ -42,7 +42,13 @@ class OracleEngine(object):
     def scale_stats(self, f):
         self.stats *= f
 
-    def global_step(self):
+    def scale_buffer(self, which, f):
+        if which == 'stats':
+            self.stats *= f
+        else:
+            self.grads *= f
+
+    def global_step(self, sync=True, jitter=0):
         d, M, D = self.d, self.M, self.D
         st = dict(sum_exp_K_mi_K_im=self.stats[:M * M].reshape(M, M).copy(), exp_K_miY=self.stats[M * M:M * M + M * D].reshape(M, D).copy(),
                   sum_YYT=self.stats[M * M + M * D], sum_exp_K_ii=self.stats[M * M + M * D + 1], KL=self.stats[M * M + M * D + 2])
@@ -75,9 +81,10 @@ def _worker(rank, world, port, regime, q):
     eng = OracleEngine(d, slice(cut[rank], cut[rank + 1]), 90)
     ev = DistributedEvaluator(eng)
     out = ev.evaluate(regime == 'B')
-    out2 = ev.evaluate(regime == 'B', kept_fraction=0.5)      # drop-out rescale path
+    out2 = ev.evaluate(regime == 'B', kept_mask=[True, False])      # node drop-out: rank 1 dropped, kept fraction 1/2
     if rank == 0:
-        q.put((out['F'], out['grad_Z'], out['grad_alpha'], out['grad_sf2'], out['grad_beta'], out2['F']))
+        q.put((out['F'], out['grad_Z'], out['grad_alpha'], out['grad_sf2'], out['grad_beta'], out2['F'], out2['grad_Z'], out2['grad_alpha'],
+               out2['grad_sf2'], out2['grad_beta']))
     dist.destroy_process_group()
 
 
@@ -105,8 +112,27 @@ def test_two_ranks_equal_one_shard(regime):
     assert np.max(np.abs(res[2] - ref['grad_alpha'])) <= 1e-9 * np.max(np.abs(ref['grad_alpha']))
     assert abs(res[3] - ref['grad_sf2']) <= 1e-9 * abs(ref['grad_sf2'])
     assert abs(res[4] - ref['grad_beta']) <= 1e-9 * abs(ref['grad_beta'])
-    # drop-out rescale (local_MapReduce.py:263-264): statistics divided by kept/(kept+dropped) = 0.5 -> doubled
-    st = Fz.phase1(d['Z'], d['sf2'], d['alpha'], d['Y'], d['X_mu'], d['X_S'])
+    # node drop-out (local_MapReduce.py:119-129, 263-264): every statistic -- the derivative sums behind grad_Z / grad_alpha
+    # included -- is summed over the kept node only (rows 0..36) and divided by kept/(kept+dropped) = 1/2
+    sl = slice(0, 37)
+    st = Fz.phase1(d['Z'], d['sf2'], d['alpha'], d['Y'][sl], d['X_mu'][sl], d['X_S'][sl])
     st2 = {k: 2.0 * v for k, v in st.items()}
-    ref2 = Fz.global_step(d['Z'], d['sf2'], d['alpha'], d['beta'], st2, 90, 4)
+    gs2 = Fz.global_step(d['Z'], d['sf2'], d['alpha'], d['beta'], st2, 90, 4)
+    p2 = Fz.phase2(d['Z'], d['sf2'], d['alpha'], d['Y'][sl], d['X_mu'][sl], d['X_S'][sl], gs2['Abar'], gs2['Bbar'], want_embeddings=False)
+    acc = dict(grad_Z_data=2.0 * p2['grad_Z_data'], grad_alpha_data=2.0 * p2['grad_alpha_data'])
+    ref2 = Fz.finish(d['Z'], d['sf2'], d['alpha'], gs2, acc, Fz.is_regime_A(d['X_S']))
     assert abs(res[5] - ref2['F']) <= 1e-10 * abs(ref2['F'])
+    assert np.max(np.abs(res[6] - ref2['grad_Z'])) <= 1e-9 * np.max(np.abs(ref2['grad_Z']))
+    assert np.max(np.abs(res[7] - ref2['grad_alpha'])) <= 1e-9 * np.max(np.abs(ref2['grad_alpha']))
+    assert abs(res[8] - ref2['grad_sf2']) <= 1e-9 * abs(ref2['grad_sf2'])
+    assert abs(res[9] - ref2['grad_beta']) <= 1e-9 * abs(ref2['grad_beta'])
+
+
+def test_draw_kept_mask_follows_the_reference():
+    """local_MapReduce.py:119-129: uniform draw per node; when everything is dropped one random node is kept and the divisor is 1/(n+1)."""
+    from gparml_amd.dist import draw_kept_mask
+    mask, f = draw_kept_mask(8, 0.5, np.random.RandomState(0))
+    drop = np.random.RandomState(0).uniform(size=8) < 0.5
+    assert mask == list(~drop) and f == float((~drop).sum()) / 8
+    mask, f = draw_kept_mask(5, 1.0, np.random.RandomState(1))
+    assert sum(mask) == 1 and f == 1.0 / 6

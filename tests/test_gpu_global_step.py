@@ -1,0 +1,123 @@
+"""Global step semantics on the device (run with -m gpu): the reference's jitter fallback (partial_terms.py:452-461), the deferred
+failure report (one host synchronisation per evaluation, in finish) and run-to-run bit-identical results (fixed-order reductions)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=0, N=300, D=3, M=40, Q=3):
+    from oracle import factorised as Fz
+    d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=seed, zseed=seed + 1, alpha_value=0.5)
+    return d, (N, D, M, Q)
+
+
+def _indefinite_stats(d, shift):
+    """Reduced statistics that make Kmm + beta*Psi2 indefinite by ``shift``: Psi2 = -(lambda_min(Kmm) + shift)/beta * I."""
+    from oracle import literal as L
+    Kmm = L.rbf_gram(d['Z'], d['sf2'], d['alpha'])
+    lam = np.linalg.eigvalsh(Kmm)[0]
+    M, D = Kmm.shape[0], d['Y'].shape[1]
+    Psi2 = -(lam + shift) / d['beta'] * np.eye(M)
+    C = np.random.RandomState(3).randn(M, D)
+    return dict(sum_YYT=float(np.sum(d['Y'] ** 2)), Psi2=Psi2, C=C, Psi0=d['sf2'] * d['Y'].shape[0], KL=0.0), Kmm
+
+
+def test_jitter_retry_matches_the_reference_branch():
+    """A barely indefinite Kmm + beta*Psi2 (smallest eigenvalue -5e-8): the reference adds 1e-7*I and carries on
+    (partial_terms.py:454-456); the device path reports GP_RETRY_JITTER once and repeats the global step with the jitter."""
+    from gparml_amd.engine import ShardEngine
+    from gparml_amd import _lib
+    from oracle import literal as L
+    d, (N, D, M, Q) = _setup()
+    st, Kmm = _indefinite_stats(d, 5e-8)
+    # the reference's own branch, restated in oracle/literal.py (logmarglik): jittered log-determinant and inverse in the trace term
+    pt = L.PartialTermsOracle(d['Z'], d['sf2'], d['alpha'], d['beta'], M, Q, N, D)
+    pt.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+    F_ref = pt.logmarglik()
+    assert np.isfinite(F_ref)
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    eng.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+    # asynchronous form: the failure surfaces at the first synchronisation point as a retry request carrying the mask
+    eng.global_step(sync=False)
+    with pytest.raises(_lib.JitterRetry) as ei:
+        eng.global_status()
+    assert ei.value.mask == 2                      # bit 1: Kmm + beta*Psi2
+    eng.global_step(sync=False, jitter=ei.value.mask)
+    eng.global_status()
+    F1 = eng.scalars()['F']
+    # synchronous form (what the partial_terms class and the MapReduce surface use) does the same internally
+    eng.global_step()
+    F2 = eng.scalars()['F']
+    assert F1 == F2
+    assert_close(F1, F_ref, 1e-6, what='F with jitter')
+    P = eng.download('KMM_PLUS_OP_INV')
+    A_j = Kmm + d['beta'] * st['Psi2'] + 1e-7 * np.eye(M)
+    assert_close(P, np.linalg.inv(A_j), 1e-5, what='inverse of the jittered matrix')
+    eng.close()
+
+
+def test_jitter_that_does_not_help_is_a_linalg_error():
+    """Smallest eigenvalue -1e-6: still indefinite with 1e-7*I -> the reference's assertion (partial_terms.py:459-461) -> LinAlgError."""
+    from gparml_amd.engine import ShardEngine
+    d, (N, D, M, Q) = _setup(seed=2)
+    st, _ = _indefinite_stats(d, 1e-6)
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    eng.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.global_step()
+    eng.global_step(sync=False)
+    eng.phase2(False)
+    with pytest.raises(Exception):                 # deferred: the evaluation's only synchronisation reports it
+        eng.finish()
+    eng.close()
+
+
+def test_evaluate_recovers_through_the_retry():
+    """ShardEngine.evaluate / DistributedEvaluator.evaluate repeat global step + phase 2 when finish() asks for the jitter."""
+    from gparml_amd.dist import DistributedEvaluator
+    from gparml_amd.engine import ShardEngine
+    d, (N, D, M, Q) = _setup(seed=4)
+    st, _ = _indefinite_stats(d, 5e-8)
+
+    class Fixed(ShardEngine):
+        def phase1(self):                          # keep the hand-made statistics instead of the shard's own
+            ShardEngine.phase1(self)
+            self.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+
+    eng = Fixed(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    a = eng.evaluate(False)
+    b = DistributedEvaluator(eng).evaluate(False)
+    assert np.isfinite(a['F']) and a['F'] == b['F']
+    assert np.all(np.isfinite(a['grad_Z'])) and np.array_equal(a['grad_Z'], b['grad_Z'])
+    eng.close()
+
+
+@pytest.mark.parametrize('regime,emb', [('A', False), ('B', True)])
+def test_repeated_evaluations_are_bit_identical(regime, emb):
+    """Every reduction on the path has a fixed order (no floating-point atomics): the same inputs give the same bits, on the same
+    context and on a fresh one."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import factorised as Fz
+    N, D, M, Q = 3000, 6, 150, 5
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=8, zseed=9, alpha_value=0.4)
+    outs = []
+    for fresh in range(2):
+        eng = ShardEngine(N, D, M, Q)
+        eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+        eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        for rep in range(3):
+            o = eng.evaluate(emb)
+            outs.append((o['F'], o['grad_Z'].copy(), o['grad_alpha'].copy(), o['grad_sf2'], o['grad_beta']))
+        eng.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[3] == outs[0][3] and o[4] == outs[0][4]
+        assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])

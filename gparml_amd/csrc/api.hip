@@ -527,7 +527,7 @@ extern "C" int gp_set_local_statistics(gp_ctx* c, double sum_YYT, const double* 
   return GP_OK;
 }
 
-// ---- not built yet -------------------------------------------------------------------------------------------------
+// ---- final gradients ---------------------------------------------------------------------------------------------
 // final = Kmm parts (global step) + all-reduced data parts (phase 2)
 __global__ void add_kernel(const double* a, const double* b, double* out, long n) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = a[i] + b[i];

@@ -162,17 +162,14 @@ __global__ void zero_kernel(double* x, long n) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] = 0.0;
 }
 
-static bool g_attr_set = false;
 
 // A: [batch][Mp][Mp] SPD in, lower Cholesky factor out (upper zeroed); Linv: L^-1; Inv: A^-1; Twork: [batch][128][Mp]
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A, double* Linv, double* Inv, double* Twork,
                           double* logdet2, double* fail_flag, double* splitk_ws) {
   const int nt = Mp / NB;
   const long ld = Mp, bs = (long)Mp * Mp;
-  if (!g_attr_set) {
-    GP_HIP(c, hipFuncSetAttribute((const void*)trinv_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + 4096) * 8));
-    g_attr_set = true;
-  }
+  // a per-device attribute: set on every call (cheap) rather than once per process -- contexts may live on several GPUs
+  GP_HIP(c, hipFuncSetAttribute((const void*)trinv_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + 4096) * 8));
   hipLaunchKernelGGL(zero_kernel, dim3(1024), dim3(256), 0, st, Linv, bs * batch);
   for (int j = 0; j < nt; ++j) {
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(1024), 0, st, A, ld, bs, j, fail_flag);

@@ -194,48 +194,9 @@ struct P1Args {
   const double* Kaug; long ld; const int* tiles; int T; int S; int cps; int total_chunks; double* part; const int* bmap;
 };
 
-__global__ void __launch_bounds__(256, 2) p1_kernel(P1Args p) {
-  const int slice = p.bmap[2 * blockIdx.x], type = p.bmap[2 * blockIdx.x + 1];   // host-built placement table
-  if (slice < 0) return;
-  const int ti = p.tiles[2 * type], tj = p.tiles[2 * type + 1];
-  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow0 = (wave >> 1) * WT, wcol0 = (wave & 1) * WT;
-  const bool skip = (ti == tj) && (wave == 2);  // mirror image of wave 1 on a diagonal tile
-  const int c0 = slice * p.cps, c1 = min(p.total_chunks, c0 + p.cps);
-  const double* Ab = p.Kaug + (long)ti * TILE + (long)c0 * KC * p.ld;
-  const double* Bb = p.Kaug + (long)tj * TILE + (long)c0 * KC * p.ld;
-  const long step = (long)KC * p.ld;
-  const int nc = c1 - c0;
-  Acc acc;
-  acc.zero();
-  const LaneOfs ofs = lane_offsets<FREE_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
-  tile_dma<FREE_CONTIG>(lds[0][0], Ab, p.ld, wave, lane);
-  tile_dma<FREE_CONTIG>(lds[0][1], Bb, p.ld, wave, lane);
-  dma_wait();
-  __syncthreads();
-  for (int c = 0; c < nc; ++c) {
-    const int cur = c & 1;
-    if (c + 1 < nc) {
-      tile_dma<FREE_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * step, p.ld, wave, lane);
-      tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * step, p.ld, wave, lane);
-    }
-    if (!skip) mma_chunk<FREE_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
-    dma_wait();
-    __syncthreads();
-  }
-  acc.drain();
-  double* out = p.part + ((long)slice * p.T + type) * (TILE * TILE);
-#pragma unroll
-  for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-    for (int bc = 0; bc < 16; ++bc)
-      out[(wrow0 + acc_row(ar, lane)) * TILE + wcol0 + acc_col(bc, lane)] = acc.v[ar][bc];
-}
-
-// Eight-wave variant of p1_kernel (the default; GP_P1_W8=0 selects the four-wave kernel): same 128x128 workgroup tile, same LDS
-// image and DMA traffic, but each 64x64 quadrant is shared by two waves (32 columns each): 32 accumulators per wave, 98 VGPRs,
-// four waves per SIMD to cover the barrier / LDS latency that two waves per SIMD leave exposed (measured 7.22 -> 6.90 ms).
+// Eight waves per 128x128 workgroup tile: each 64x64 quadrant is shared by two waves (32 columns each): 32 accumulators per wave,
+// 100 VGPRs, four waves per SIMD to cover the barrier / LDS latency that two waves per SIMD leave exposed (a four-wave variant with
+// 64x64 wave tiles measured 7.22 ms against 6.90 ms).
 __global__ void __launch_bounds__(512, 4) p1_kernel8(P1Args p) {
   const int slice = p.bmap[2 * blockIdx.x], type = p.bmap[2 * blockIdx.x + 1];
   if (slice < 0) return;
@@ -439,10 +400,7 @@ int run_phase1(gp_ctx* c) {
   p.bmap = c->bmap;
   const int blocks = c->bmap_blocks;
   (void)hipEventRecord(c->ev[10], c->stream);
-  static int w8 = -1;
-  if (w8 < 0) { const char* e = getenv("GP_P1_W8"); w8 = e ? atoi(e) : 1; }
-  if (w8) hipLaunchKernelGGL(p1_kernel8, dim3(blocks), dim3(512), 0, c->stream, p);
-  else hipLaunchKernelGGL(p1_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+  hipLaunchKernelGGL(p1_kernel8, dim3(blocks), dim3(512), 0, c->stream, p);
   (void)hipEventRecord(c->ev[11], c->stream);
   GP_HIP(c, hipGetLastError());
   double* Psi2 = c->stats;

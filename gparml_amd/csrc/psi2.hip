@@ -777,12 +777,9 @@ template <int QT>
 static int launch_cols_mfma(gp_ctx* c, const PB2Args& a) {
   constexpr int LDZ = QT + 2;
   const size_t smem = ((size_t)(2 * 32 + 4 * 16) * LDZ + c->Mp + 4 * (3 * QT + 1)) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_cols_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
   if (smem > 160 * 1024) return fail(c, GP_ERR_UNSUPPORTED, "regime B, Q >= 25: M = %d needs %zu bytes of LDS", c->M, smem);
+  // a per-device attribute: set on every launch (cheap) rather than once per process -- contexts may live on several GPUs
+  GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_cols_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((psi2_cols_mfma_kernel<QT>), dim3(c->pb_blocks, c->nslab), dim3(256), smem, c->stream, a, (const double*)c->Z1P,
                      (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
                      (const double*)c->alphaP);

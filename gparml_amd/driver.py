@@ -18,6 +18,9 @@ import time
 
 import numpy
 
+from ._lib import JitterRetry
+
+
 def _f(x):
     return float(numpy.asarray(x).reshape(-1)[0])
 
@@ -46,6 +49,68 @@ def transform_grad(b, x):
     return 1
 
 
+def positive_mask(bounds):
+    """Boolean mask of the (0, None)-bounded entries of a flat parameter vector."""
+    return numpy.array([b == (0, None) for b in bounds], dtype=bool)
+
+
+def transform_vec(mask, x):
+    """``[transform(b, x_i)]`` over a whole flat vector at once (supporting_functions.py:127-132): softplus on the positive entries,
+    identity elsewhere, the same range assertion.  The per-element Python loop costs ~50 k calls per evaluation at M*Q = 51 200."""
+    x = numpy.asarray(x, dtype=float)
+    out = x.copy()
+    xp = x[mask]
+    assert numpy.all((-LIM_VAL < xp) & (xp < LIM_VAL))
+    out[mask] = numpy.log(1 + numpy.exp(xp))
+    return out
+
+
+def transform_grad_vec(mask, x):
+    """``[transform_grad(b, x_i)]`` as a vector (supporting_functions.py:143-148)."""
+    x = numpy.asarray(x, dtype=float)
+    out = numpy.ones_like(x)
+    xp = x[mask]
+    assert numpy.all((-LIM_VAL < xp) & (xp < LIM_VAL))
+    out[mask] = 1 / (numpy.exp(-xp) + 1)
+    return out
+
+
+def init_statistics(map_reduce, options):
+    """parallel_GPLVM.init_statistics (:134-214): the names the backends pass around, the initial global statistics -- inducing points
+    Z by k-means over the first shards' embeddings (scipy.cluster.vq.kmeans, topped up with the first embeddings when k-means returns
+    fewer than M centres) plus 0.05 * randn, sf2 = alpha = beta = 1 (:179-194), or the ``*_f.npy`` files of a previous run with
+    ``options['load']`` (:195-200) -- and the optimisation bounds.  Returns (options, global_statistics).  One-off host work."""
+    M, Q = options['M'], options['Q']
+    Driver(options, map_reduce)          # fills the *_names entries and the flat bounds exactly as the evaluations expect them
+    if not options.get('load'):
+        names = sorted(os.listdir(options['input'] + '/'))
+        idx = 0
+        embeddings = map_reduce.load(options['embeddings'] + '/' + names[idx] + '.embedding.npy')
+        while embeddings.shape[0] < M:                                                  # :172-176
+            idx += 1
+            embeddings = numpy.concatenate((embeddings, map_reduce.load(options['embeddings'] + '/' + names[idx] + '.embedding.npy')))
+        if embeddings.shape[1] != Q:
+            raise Exception('Given Q does not equal existing embedding data dimensions!')
+        import scipy.cluster.vq as cl
+        Z = cl.kmeans(embeddings, M)[0]                                                 # :180-181
+        missing = M - Z.shape[0]
+        if missing > 0:
+            Z = numpy.concatenate((Z, embeddings[:missing]))                            # :183-185
+        Z = Z + numpy.random.randn(M, Q) * 0.05                                         # :187
+        gs = {'Z': Z, 'sf2': numpy.array([[1.0]]), 'alpha': numpy.ones((1, Q)), 'beta': numpy.array([[1.0]])}
+    else:
+        gs = {key: map_reduce.load(options['statistics'] + '/global_statistics_' + key + '_f.npy')
+              for key in options['global_statistics_names']}
+    return options, gs
+
+
+def initial_flat_vector(options, global_statistics):
+    """The optimiser's starting point (parallel_GPLVM.py:98-100): flat order Z, sf2, alpha, beta with the positive entries mapped
+    through transform_back (softplus inverse)."""
+    flat = numpy.concatenate([numpy.asarray(global_statistics[k], dtype=float).flatten() for k in ('Z', 'sf2', 'alpha', 'beta')])
+    return numpy.array([transform_back(b, v) for b, v in zip(options['flat_global_statistics_bounds'], flat)])
+
+
 class Driver(object):
     def __init__(self, options, map_reduce=None, fast=True):
         if map_reduce is None:
@@ -65,6 +130,7 @@ class Driver(object):
         o['partial_derivatives_names'] = ['F', 'dF_dsum_exp_K_ii', 'dF_dKmm', 'dF_dsum_exp_K_miY', 'dF_dsum_exp_K_mi_K_im']
         o['cache_names'] = ['Kmm', 'Kmm_inv']
         o['flat_global_statistics_bounds'] = ([(None, None)] * (o['M'] * o['Q']) + [(0, None)] + [(0, None)] * o['Q'] + [(0, None)])
+        self._pos = positive_mask(o['flat_global_statistics_bounds'])
         o.setdefault('keep', True)
         o.setdefault('fixed_beta', False)
         o.setdefault('drop_out_fraction', 0)
@@ -94,8 +160,7 @@ class Driver(object):
     # ---- parallel_GPLVM.py:222-279
     def likelihood_and_gradient(self, flat_array, iteration, step_size=0):
         o, mr = self.options, self.map_reduce
-        bounds = o['flat_global_statistics_bounds']
-        flat_t = numpy.array([transform(b, x) for b, x in zip(bounds, flat_array)])
+        flat_t = transform_vec(self._pos, flat_array)
         gs = self.rebuild_global_statistics(flat_t)
         o['i'] = iteration
         o['step_size'] = step_size
@@ -107,7 +172,7 @@ class Driver(object):
         else:
             F, gradient = self._evaluate_compat(gs)
         grad = self.flatten_global_statistics(gradient)
-        grad = numpy.array([g * transform_grad(b, x) for b, x, g in zip(bounds, flat_array, grad)])
+        grad = grad * transform_grad_vec(self._pos, flat_array)
         return -1 * F, -1 * grad
 
     # ---- the reference's sequence through the backend surface (parallel_GPLVM.py:243-265, 302-369)
@@ -151,22 +216,38 @@ class Driver(object):
         o, mr = self.options, self.map_reduce
         t0 = time.time()
         files = mr._input_files(o)
-        engines = [mr._prepare_shard(o, f, gs) for f in files]
+        engines = mr._prepare_shards(o, files, gs)
+        # node drop-out (local_MapReduce.py:119-129, 263-264): the same draw as statistics_MR; dropped shards contribute to neither
+        # reduction and both reduced buffers are divided by kept/(kept+dropped)
+        kept, frac = list(range(len(files))), None
+        if o.get('drop_out_fraction', 0) > 0:
+            kept, frac = mr._draw_drop_out(len(files), o['drop_out_fraction'])
+        mr._for_each(engines, lambda e: e.phase1())
+        root = engines[kept[0]]
+        for i in kept[1:]:
+            root.combine(engines[i], 'stats', 'add')            # statistics_reducer on the device(s)
+        if frac is not None:
+            root.scale_buffer('stats', 1.0 / frac)
         for e in engines:
-            e.phase1()
-        root = engines[0]
-        for e in engines[1:]:
-            root.combine(e, 'stats', 'add')            # statistics_reducer on the device
-        for e in engines[1:]:
-            e.combine(root, 'stats', 'copy')           # every shard needs the global sums (local_MapReduce.py:318-320)
+            if e is not root:
+                e.combine(root, 'stats', 'copy')       # every shard needs the global sums (local_MapReduce.py:318-320)
         t1 = time.time()
         want_emb = not o['fixed_embeddings']
-        for e in engines:
-            e.global_step()                            # replicated M x M algebra
-            e.phase2(want_emb)
-        for e in engines[1:]:
-            root.combine(e, 'grads', 'add')
-        res = root.finish()
+        jitter = 0
+        while True:
+            def second(e):
+                e.global_step(sync=False, jitter=jitter)   # replicated M x M algebra
+                e.phase2(want_emb)
+            mr._for_each(engines, second)
+            for i in kept[1:]:
+                root.combine(engines[i], 'grads', 'add')
+            if frac is not None:
+                root.scale_buffer('grads', 1.0 / frac)
+            try:
+                res = root.finish()
+                break
+            except JitterRetry as r:
+                jitter = r.mask
         sc = root.scalars()
         # the artefacts other tools read (--load, predict.py): the five base sums and the partial derivatives
         it = str(o['i'])

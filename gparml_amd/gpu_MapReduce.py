@@ -125,6 +125,53 @@ def _globals(options):
     return gs
 
 
+def _devices(options):
+    """GPUs the shards are spread over: options['devices'] (a list of device indices) or the single options['device'] (default 0).
+    The reference runs one pool worker per shard (local_MapReduce.py:134,155,299); here shard i lives on devices[i % len(devices)]."""
+    devs = options.get('devices')
+    if devs:
+        return [int(d) for d in devs]
+    return [int(options.get('device', 0))]
+
+
+def _device_of(options, input_file_name):
+    files = _input_files(options)
+    devs = _devices(options)
+    try:
+        return devs[files.index(input_file_name) % len(devs)]
+    except ValueError:
+        return devs[0]
+
+
+def _for_each(items, fn):
+    """Apply fn to every item -- from one thread per item when there are several (the ctypes calls release the GIL, so shards on
+    different GPUs run concurrently: the Pool.map of local_MapReduce.py:134-137); results in order, the first exception re-raised."""
+    items = list(items)
+    if len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(items)) as ex:
+        return list(ex.map(fn, items))
+
+
+def _prepare_shards(options, files, global_statistics):
+    return _for_each(files, lambda f: _prepare_shard(options, f, global_statistics))
+
+
+def _draw_drop_out(n_nodes, fraction):
+    """The keep/drop draw of statistics_MR (local_MapReduce.py:119-129) from numpy's global generator, like the reference.  Returns the
+    kept indices and the divisor kept/(kept+dropped); sets the module globals the reference keeps between its two MapReduces.  When
+    every node is dropped the reference keeps one random node but leaves ALL n nodes in dropped_out_nodes: divisor 1/(n+1)."""
+    global non_dropped_out_nodes, dropped_out_nodes
+    drop = numpy.random.uniform(size=n_nodes) < fraction
+    dropped_out_nodes = numpy.arange(n_nodes)[drop]
+    non_dropped_out_nodes = numpy.arange(n_nodes)[~drop]
+    if len(non_dropped_out_nodes) == 0:
+        non_dropped_out_nodes = [numpy.random.randint(0, n_nodes)]
+    frac = float(len(non_dropped_out_nodes)) / (len(non_dropped_out_nodes) + len(dropped_out_nodes))
+    return [int(i) for i in non_dropped_out_nodes], frac
+
+
 def _prepare_shard(options, input_file_name, global_statistics):
     """Everything statistics_mapper / embeddings_mapper do before partial_terms.set_data
     (local_MapReduce.py:189-214, 315-341): resident Y, embeddings, trial point, globals."""
@@ -137,7 +184,7 @@ def _prepare_shard(options, input_file_name, global_statistics):
         if sh is not None:
             sh['engine'].close()
         Y = _read_csv(input_file_name)
-        eng = ShardEngine(Y.shape[0], options['D'], options['M'], options['Q'], device=options.get('device', 0))
+        eng = ShardEngine(Y.shape[0], options['D'], options['M'], options['Q'], device=_device_of(options, input_file_name))
         eng.upload_shard(Y, X_mu, X_S, xs_is_raw=not options['fixed_embeddings'])
         sh = _shards[key] = dict(engine=eng, shape=(Y.shape[0], options['D'], options['M'], options['Q']))
     else:
@@ -191,27 +238,21 @@ def statistics_MR(options):
     """local_MapReduce.statistics_MR (:115-171): map every shard, reduce by key, write accumulated_statistics files."""
     global non_dropped_out_nodes, dropped_out_nodes
     input_files = _input_files(options)
+    frac = None
     if options.get('drop_out_fraction', 0) > 0:                                      # :119-129
-        drop = numpy.random.uniform(size=len(input_files)) < options['drop_out_fraction']
-        dropped_out_nodes = numpy.arange(len(input_files))[drop]
-        non_dropped_out_nodes = numpy.arange(len(input_files))[~drop]
-        if len(non_dropped_out_nodes) == 0:
-            non_dropped_out_nodes = [numpy.random.randint(0, len(input_files))]
-            dropped_out_nodes = [i for i in range(len(input_files)) if i != non_dropped_out_nodes[0]]
-        input_files = [input_files[i] for i in non_dropped_out_nodes]
-    mapped, mapper_times = [], []
-    for f in input_files:
-        out, t = statistics_mapper((f, options))
-        mapped.append(out)
-        mapper_times.append(t)
+        kept, frac = _draw_drop_out(len(input_files), options['drop_out_fraction'])
+        input_files = [input_files[i] for i in kept]
+    responses = _for_each(input_files, lambda f: statistics_mapper((f, options)))   # one worker per shard, :131-137
+    mapped = [r[0] for r in responses]
+    mapper_times = [r[1] for r in responses]
     files, reducer_times = [], []
     for key in mapped[0].keys():                                                     # statistics_reducer, :250-277
         start = time.time()
         acc = mapped[0][key]
         for m in mapped[1:]:
             acc = acc + m[key]
-        if options.get('drop_out_fraction', 0) > 0:
-            acc = acc / (float(len(non_dropped_out_nodes)) / (len(non_dropped_out_nodes) + len(dropped_out_nodes)))
+        if frac is not None:                                                          # :263-264, 272-273
+            acc = acc / frac
         name = options['statistics'] + '/accumulated_statistics_' + key + '_' + str(options['i']) + '.npy'
         save(name, acc)
         files.append((key, name))
@@ -241,7 +282,8 @@ def embeddings_mapper(arg):
 
 
 def embeddings_MR(options):
-    return [embeddings_mapper((f, options)) for f in _input_files(options)]          # :284-308
+    files = _input_files(options)                                                    # all nodes, dropped or not (:293-295)
+    return _for_each(files, lambda f: embeddings_mapper((f, options)))                # :284-308
 
 
 # ------------------------------------------------------------------------------------------------- cache / partial_terms
@@ -249,7 +291,7 @@ def load_partial_terms(options, global_statistics):
     # local_MapReduce.py:403-409
     return _partial_terms(global_statistics['Z'], _f(global_statistics['sf2']), numpy.squeeze(global_statistics['alpha']).reshape(-1),
                           _f(global_statistics['beta']), options['M'], options['Q'], options['N'], options['D'],
-                          update_global_statistics=False, device=options.get('device', 0))
+                          update_global_statistics=False, device=_devices(options)[0])
 
 
 def cache(options, global_statistics):

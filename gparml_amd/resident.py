@@ -7,7 +7,8 @@ resident vectors.  Across GPUs (one process per GPU) the local scalars are summe
 """
 import numpy as np
 
-from .driver import transform, transform_grad
+from ._lib import JitterRetry
+from .driver import positive_mask, transform_grad_vec, transform_vec
 from .engine import ShardEngine
 
 
@@ -29,7 +30,10 @@ class ResidentModel(object):
         n_local = sum(e.N_s for e in self.engines)
         self.N = int(N_global) if N_global is not None else int(self._allreduce_scalar(float(n_local)))
         self.bounds = [(None, None)] * (M * Q) + [(0, None)] + [(0, None)] * Q + [(0, None)]
+        self._pos = positive_mask(self.bounds)
         self._dev_tensors = None
+        self.version = 0            # bumped whenever the resident vectors may have changed (ResidentCG caches its reductions on it)
+        self.n_collectives = 0      # all-reduces issued so far (tests assert the per-iteration count)
 
     @staticmethod
     def _dist_ready():
@@ -40,12 +44,18 @@ class ResidentModel(object):
             return False
 
     def _allreduce_scalar(self, v, op='sum'):
+        return float(self._allreduce_vector([v], op)[0])
+
+    def _allreduce_vector(self, values, op='sum'):
+        """One collective for a small vector of local scalars (sum or max over ranks)."""
+        values = np.asarray(values, dtype=np.float64)
         if self._dist is None:
-            return v
+            return values
         import torch
-        t = torch.tensor([v], dtype=torch.float64, device='cuda' if self._dist.get_backend() == 'nccl' else 'cpu')
+        t = torch.tensor(values, dtype=torch.float64, device='cuda' if self._dist.get_backend() == 'nccl' else 'cpu')
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == 'sum' else self._dist.ReduceOp.MAX, group=self.group)
-        return float(t.item())
+        self.n_collectives += 1
+        return t.cpu().numpy()
 
     def _allreduce_buffers(self, which):
         if self._dist is None:
@@ -56,6 +66,7 @@ class ResidentModel(object):
         p, n = root.stats_buffer() if which == 'stats' else root.grads_buffer()
         t = device_tensor(p, n, torch.device('cuda', root.device))
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        self.n_collectives += 1
 
     def close(self):
         for e in self.engines:
@@ -65,7 +76,7 @@ class ResidentModel(object):
     # ---- parallel_GPLVM.likelihood_and_gradient (:222-279) on resident shards
     def likelihood_and_gradient(self, flat_array, iteration, step_size=0):
         M, Q = self.M, self.Q
-        xt = np.array([transform(b, v) for b, v in zip(self.bounds, flat_array)])
+        xt = transform_vec(self._pos, flat_array)
         Z = xt[:M * Q].reshape(M, Q)
         sf2, alpha, beta = xt[M * Q], xt[M * Q + 1:M * Q + 1 + Q], xt[M * Q + 1 + Q]
         want_emb = not self.fixed_embeddings
@@ -78,15 +89,22 @@ class ResidentModel(object):
         self._allreduce_buffers('stats')
         for e in self.engines[1:]:
             e.combine(root, 'stats', 'copy')
-        for e in self.engines:
-            e.global_step()
-            e.phase2(want_emb)
-        for e in self.engines[1:]:
-            root.combine(e, 'grads', 'add')
-        self._allreduce_buffers('grads')
-        res = root.finish()
+        jitter = 0
+        while True:
+            for e in self.engines:
+                e.global_step(sync=False, jitter=jitter)
+                e.phase2(want_emb)
+            for e in self.engines[1:]:
+                root.combine(e, 'grads', 'add')
+            self._allreduce_buffers('grads')
+            try:
+                res = root.finish()         # the evaluation's only host synchronisation
+                break
+            except JitterRetry as r:        # same reduced statistics on every rank: all ranks retry together (partial_terms.py:452-456)
+                jitter = r.mask
+        self.version += 1                   # grad_latest changed
         grad = np.concatenate([res['grad_Z'].ravel(), [res['grad_sf2']], res['grad_alpha'], [0.0 if self.fixed_beta else res['grad_beta']]])
-        grad = np.array([g * transform_grad(b, v) for b, v, g in zip(self.bounds, flat_array, grad)])
+        grad = grad * transform_grad_vec(self._pos, flat_array)
         return -res['F'], -grad
 
 
@@ -96,23 +114,29 @@ class ResidentCG(object):
 
     def __init__(self, model):
         self.m = model
-        self._cache = None
+        self._cache = None      # (model.version, the six reductions)
 
     def _dots(self):
+        """[mu, kappa, theta, |g_new|^2, g_new.g_old, max|d|] over all shards of all ranks: one pass over the resident vectors and
+        two small collectives -- a packed SUM of five scalars and one MAX (scg_adapted_local_MapReduce.py:59-155 visits every
+        shard's files once per quantity) -- cached until a vector changes (any update here, or a new evaluation's grad_latest)."""
+        if self._cache is not None and self._cache[0] == self.m.version:
+            return self._cache[1]
         tot = np.zeros(6)
         for e in self.m.engines:
             d = e.cg_dots()
             tot[:5] += d[:5]
             tot[5] = max(tot[5], d[5])
         if self.m._dist is not None:
-            for k in range(5):
-                tot[k] = self.m._allreduce_scalar(tot[k])
-            tot[5] = self.m._allreduce_scalar(tot[5], 'max')
+            tot[:5] = self.m._allreduce_vector(tot[:5], 'sum')
+            tot[5] = self.m._allreduce_vector(tot[5:6], 'max')[0]
+        self._cache = (self.m.version, tot)
         return tot
 
     def _upd(self, which, a=0.0):
         for e in self.m.engines:
             e.cg_update(which, a)
+        self.m.version += 1
 
     def embeddings_set_grads(self, folder=None):
         self._upd(ShardEngine.CG_SET_GRADS)
@@ -157,12 +181,16 @@ class ResidentGD(object):
 
     def __init__(self, model):
         self.m = model
+        self._cache = None      # (model.version, (sum |grad_now|, max |grad_now|))
 
     def _upd(self, which, a=0.0):
         for e in self.m.engines:
             e.cg_update(which, a)
+        self.m.version += 1
 
     def _abs(self):
+        if self._cache is not None and self._cache[0] == self.m.version:
+            return self._cache[1]
         s, mx = 0.0, 0.0
         for e in self.m.engines:
             a = e.cg_abs()
@@ -171,7 +199,9 @@ class ResidentGD(object):
         if self.m._dist is not None:
             s = self.m._allreduce_scalar(s)
             mx = self.m._allreduce_scalar(mx, 'max')
+        self._cache = (self.m.version, (s, mx))
         return s, mx
+
 
     def embeddings_set_grads(self, folder=None):                       # :14-32  grad_now = latest, d = -latest
         self._upd(ShardEngine.CG_SET_GRADS)

@@ -11,11 +11,22 @@ import numpy as np
 RECOVERABLE = (np.linalg.LinAlgError, ZeroDivisionError, ValueError, Warning, AssertionError, FloatingPointError)
 
 
+_fail_count = 0               # consecutive failures, scg_adapted.py:44
+_allowed_failures = 100       # scg_adapted.py:45
+
+
 def safe_f_and_grad_f(f_and_gradf, x, iteration=0, step_size=0, *optargs):
-    """scg_adapted.py:44-76: numerical failures become f = inf, grad = ones."""
+    """scg_adapted.py:46-76: a numerical failure becomes f = inf, grad = ones -- at most ``_allowed_failures`` times in a row, after
+    which the exception is re-raised ("Too many errors..."); a successful evaluation resets the count."""
+    global _fail_count
     try:
-        return f_and_gradf(x, iteration, step_size, *optargs)
+        out = f_and_gradf(x, iteration, step_size, *optargs)
+        _fail_count = 0
+        return out
     except RECOVERABLE:
+        if _fail_count >= _allowed_failures:
+            raise
+        _fail_count += 1
         return np.inf, np.ones(x.shape[0])
 
 

@@ -109,6 +109,19 @@ for fname, optimiser, iters in (('pipe_gplvm_2shards.npz', 'scg', 2), ('gdpipe_g
         assert np.max(np.abs(x - g['call%%d_x' %% k])) <= 1e-7 * np.max(np.abs(g['call%%d_x' %% k])) + 1e-12, (optimiser, k, 'x')
         assert abs(f - float(g['call%%d_f' %% k])) <= 1e-6 * abs(float(g['call%%d_f' %% k])), (optimiser, k, 'f')
         assert np.max(np.abs(grad - g['call%%d_g' %% k])) <= 2e-5 * np.max(np.abs(g['call%%d_g' %% k])), (optimiser, k, 'g')
+    if optimiser == 'scg':
+        # the optimiser's per-shard reductions (scg_adapted_local_MapReduce.py:59-155): all six quantities from ONE pass and TWO small
+        # collectives (packed SUM of five + one MAX), cached until a resident vector changes
+        cg = ResidentCG(model)
+        n0 = model.n_collectives
+        vals = [cg.embeddings_get_grads_mu(), cg.embeddings_get_grads_kappa(), cg.embeddings_get_grads_theta(),
+                cg.embeddings_get_grads_current_grad(), cg.embeddings_get_grads_gamma(), cg.embeddings_get_grads_max_d(None, 0.5)]
+        assert model.n_collectives - n0 == 2, model.n_collectives - n0
+        cg.embeddings_set_grads_update_d(None, 0.1)
+        assert cg.embeddings_get_grads_kappa() != vals[1] and model.n_collectives - n0 == 4
+        n1 = model.n_collectives
+        model.likelihood_and_gradient(x_opt, 'f')
+        assert model.n_collectives - n1 == 2            # one evaluation = the two packed buffer all-reduces
     model.close()
 dist.destroy_process_group()
 print('RANK_OK', rank)

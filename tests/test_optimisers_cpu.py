@@ -101,3 +101,64 @@ def test_split_vectors_follow_the_joint_trajectory(optimiser):
     np.testing.assert_allclose(flog_s, flog_j, rtol=1e-9)
     np.testing.assert_allclose(np.concatenate((xs, ops.X)), xj, rtol=1e-7, atol=1e-9)
     assert flog_j[-1] < flog_j[0]
+
+
+def test_failure_cap_of_the_safe_wrapper():
+    """scg_adapted.py:44-76: 100 consecutive failures are absorbed (f = inf, grad = ones), the 101st is re-raised; a success resets."""
+    from gparml_amd import scg_adapted as S
+    S._fail_count = 0
+    calls = {'n': 0}
+
+    def bad(x, it, step):
+        calls['n'] += 1
+        raise np.linalg.LinAlgError('singular')
+
+    x = np.zeros(3)
+    for _ in range(S._allowed_failures):
+        f, g = S.safe_f_and_grad_f(bad, x)
+        assert f == np.inf and np.array_equal(g, np.ones(3))
+    with pytest.raises(np.linalg.LinAlgError):
+        S.safe_f_and_grad_f(bad, x)
+    assert calls['n'] == S._allowed_failures + 1
+    S._fail_count = 50
+    assert S.safe_f_and_grad_f(lambda x, it, step: (1.0, x), x)[0] == 1.0 and S._fail_count == 0
+
+
+def test_init_statistics_follows_the_reference(tmp_path):
+    """parallel_GPLVM.init_statistics (:134-214): k-means inducing points + 0.05 randn, unit hyper-parameters, bounds, --load branch."""
+    from gparml_amd import driver as Dr
+
+    class Files(object):
+        load = staticmethod(np.load)
+        save = staticmethod(np.save)
+
+    rs = np.random.RandomState(0)
+    for d in ('input', 'embeddings', 'statistics'):
+        (tmp_path / d).mkdir()
+    emb = []
+    for i in range(2):
+        (tmp_path / 'input' / ('shard_%d' % i)).write_text('0\n')
+        e = rs.randn(30, 3) + 4.0 * (i == 1)
+        np.save(str(tmp_path / 'embeddings' / ('shard_%d.embedding.npy' % i)), e)
+        emb.append(e)
+    opts = dict(input=str(tmp_path / 'input'), embeddings=str(tmp_path / 'embeddings'), statistics=str(tmp_path / 'statistics'), M=40, Q=3,
+                load=False)
+    np.random.seed(3)
+    opts, gs = Dr.init_statistics(Files, opts)
+    assert gs['Z'].shape == (40, 3) and gs['alpha'].shape == (1, 3) and float(gs['sf2']) == 1.0 and float(gs['beta']) == 1.0
+    # the same draws by hand: k-means over BOTH shards (the first has fewer than M points, :172-176), then the jitter
+    import scipy.cluster.vq as cl
+    np.random.seed(3)
+    allp = np.concatenate(emb)
+    Zk = cl.kmeans(allp, 40)[0]
+    if Zk.shape[0] < 40:
+        Zk = np.concatenate((Zk, allp[:40 - Zk.shape[0]]))
+    np.testing.assert_allclose(gs['Z'], Zk + np.random.randn(40, 3) * 0.05)
+    assert len(opts['flat_global_statistics_bounds']) == 40 * 3 + 1 + 3 + 1
+    x0 = Dr.initial_flat_vector(opts, gs)
+    np.testing.assert_allclose(np.log(1 + np.exp(x0[-1])), 1.0)
+    for key in ('Z', 'sf2', 'alpha', 'beta'):
+        np.save(str(tmp_path / 'statistics' / ('global_statistics_%s_f.npy' % key)), gs[key] * 2.0)
+    opts['load'] = True
+    _, gs2 = Dr.init_statistics(Files, opts)
+    np.testing.assert_array_equal(gs2['Z'], gs['Z'] * 2.0)

@@ -24,6 +24,8 @@ class ResidentModel(object):
             self.engines.append(e)
         self.group = dist_group
         self._dist = None
+        self.version = 0            # bumped whenever the resident vectors may have changed (ResidentCG caches its reductions on it)
+        self.n_collectives = 0      # all-reduces issued so far (tests assert the per-iteration count)
         if dist_group is not None or self._dist_ready():
             import torch.distributed as dist
             self._dist = dist
@@ -32,8 +34,6 @@ class ResidentModel(object):
         self.bounds = [(None, None)] * (M * Q) + [(0, None)] + [(0, None)] * Q + [(0, None)]
         self._pos = positive_mask(self.bounds)
         self._dev_tensors = None
-        self.version = 0            # bumped whenever the resident vectors may have changed (ResidentCG caches its reductions on it)
-        self.n_collectives = 0      # all-reduces issued so far (tests assert the per-iteration count)
 
     @staticmethod
     def _dist_ready():

@@ -224,3 +224,65 @@ def synthetic_shard(N, D, M, Q, regime='A', seed=0, zseed=1, alpha_value=None):
     if alpha_value is None:
         alpha_value = min(1.0, 1.0 / Q)
     return dict(Y=Y, X_mu=X_mu, X_S=X_S, Z=Z, sf2=1.0, alpha=np.full(Q, float(alpha_value)), beta=10.0)
+
+
+# ----------------------------------------------------------------------------------------- BLAS-bound CPU baseline
+def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixed_beta=False, work=None):
+    """Regime A with fixed embeddings (X_S == 0, no per-point gradients) arranged so that the time goes into DGEMM: the same
+    formulation as phase1 / global_step / phase2 / finish above, but K_nm is generated once per chunk and KEPT for phase 2 (the
+    two-phase protocol regenerates it), the two back-propagation products are GEMMs on K and Y into one buffer, element-wise work is
+    done in place in buffers that are reused from chunk to chunk (``work``: pass the same dict again to reuse them across calls),
+    and grad_alpha's mu^2 term uses the row sums of W.  This is what bench.py times as the CPU baseline (kind "port"): large chunks,
+    all BLAS threads.  Checked against evaluate() by tests/test_oracle_factorised.py."""
+    Z, s2, a, b = _as_params(Z, sf2, alpha, beta)
+    N_s, D = Y.shape
+    M, Q = Z.shape
+    Ng = N_s if N_global is None else N_global
+    work = {} if work is None else work
+    nch = (N_s + chunk - 1) // chunk
+    if work.get('shape') != (N_s, M, chunk):
+        work.clear()
+        work['shape'] = (N_s, M, chunk)
+        work['K'] = [np.empty((min(chunk, N_s - i * chunk), M)) for i in range(nch)]
+        work['W'] = np.empty((min(chunk, N_s), M))
+    Z2a = (Z * Z).dot(a)                                        # sum_q a_q z_mq^2
+    Za = (Z * a[None, :]).T.copy()                              # (Q, M)
+    Psi2 = np.zeros((M, M))
+    C = np.zeros((M, D))
+    sum_YYT = 0.0
+    for i in range(nch):
+        lo, hi = i * chunk, min(N_s, (i + 1) * chunk)
+        mu, Yc, E = X_mu[lo:hi], Y[lo:hi], work['K'][i]
+        np.dot(mu, Za, out=E)                                   # (n, M)
+        E *= 2.0
+        E -= (mu * mu).dot(a)[:, None]
+        E -= Z2a[None, :]
+        E *= 0.5
+        np.exp(E, out=E)
+        if s2 != 1.0:
+            E *= s2
+        Psi2 += E.T.dot(E)
+        C += E.T.dot(Yc)
+        sum_YYT += float(np.einsum('ij,ij->', Yc, Yc))
+    st = dict(sum_exp_K_mi_K_im=Psi2, exp_K_miY=C, sum_YYT=sum_YYT, sum_exp_K_ii=s2 * N_s, KL=0.0)
+    gs = global_step(Z, sf2, alpha, beta, st, Ng, D, fixed_beta)
+    B2 = 2.0 * gs['Bbar']
+    At = np.ascontiguousarray(gs['Abar'].T)                     # G = K (2 Bbar) + Y Abar^T
+    R1 = np.zeros((M, Q))
+    R0 = np.zeros(M)
+    hmu2 = np.zeros(Q)
+    for i in range(nch):
+        lo, hi = i * chunk, min(N_s, (i + 1) * chunk)
+        K, mu, Yc = work['K'][i], X_mu[lo:hi], Y[lo:hi]
+        W = work['W'][:hi - lo]
+        np.dot(K, B2, out=W)
+        W += Yc.dot(At)
+        W *= K                                                  # W = G o K
+        R1 += W.T.dot(mu)
+        R0 += W.sum(0)
+        hmu2 += W.sum(1).dot(mu * mu)
+    gZ = a[None, :] * (R1 - Z * R0[:, None])
+    ga = -0.5 * (hmu2 - 2.0 * np.sum(Z * R1, axis=0) + (Z * Z).T.dot(R0))
+    out = finish(Z, sf2, alpha, gs, dict(grad_Z_data=gZ, grad_alpha_data=ga), True)
+    out['stats'], out['gstep'] = st, gs
+    return out

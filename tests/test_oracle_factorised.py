@@ -88,3 +88,16 @@ def test_finite_difference_sanity():
     assert abs((F(X_mu=mp) - base['F']) / h - base['grad_X_mu'][3, 1]) < 1e-3 * max(1.0, abs(base['grad_X_mu'][3, 1]))
     Sp = d['X_S'].copy(); Sp[2, 0] += h
     assert abs((F(X_S=Sp) - base['F']) / h - base['grad_X_S'][2, 0]) < 1e-3 * max(1.0, abs(base['grad_X_S'][2, 0]))
+
+
+def test_blas_bound_baseline_equals_the_two_phase_port():
+    """bench.py's CPU baseline (evaluate_blas: K kept between the phases, buffers reused) is the same evaluation as evaluate()."""
+    from oracle import factorised as Fz
+    d = Fz.synthetic_shard(5000, 7, 60, 6, regime='A', seed=3, zseed=4, alpha_value=0.4)
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=False)
+    work = {}
+    for chunk in (1024, 5000):
+        out = Fz.evaluate_blas(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], chunk=chunk, work=work)
+        assert abs(out['F'] - ref['F']) <= 1e-11 * abs(ref['F'])
+        for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'):
+            assert np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) <= 1e-8 * np.max(np.abs(ref[k])), k

@@ -40,13 +40,12 @@ for key,name in (('p2_fast','p2_kernel'),('p1_kernel','p1_kernel'),('psi1_kernel
     if f is not None and w is not None:
         # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) streaming reads -> x2 (MI355X_MICROARCH.md, HBM)
         tr[name+'_hbm_bytes_per_launch']=(2.0*f+w)*1024.0; tr[name+'_fetch_kb_raw']=f; tr[name+'_write_kb_raw']=w
+import subprocess, datetime
+tr['kernel']='gp::p2_fast8_kernel<3>'; tr['N']=1000000; tr['D']=100; tr['M']=512; tr['Q']=10
+tr['date']=datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%MZ')
+tr['command']='tools/r02_prof.sh (bench.py --steps 3 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 json.dump(tr, open('$O/traffic.json','w'), indent=1)
 print(tr)
 PY
 rm -rf $O/*/*kernel_trace.csv $O/*/*agent_info.csv
 cd $R
-for v in "GP_P2_ABLATE=1" "GP_P2_VARIANT=4" "GP_P2_VARIANT=0"; do
-  echo "== $v" >> $O/ablate.log
-  env $v python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['device_ms'])" >> $O/ablate.log
-done
-cat $O/ablate.log

@@ -1,6 +1,7 @@
 # rocprofv3 kernel-trace + stats of the default bench command; summary copied to gpurun_out/prof_bench
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 mkdir -p $R/gpurun_out/prof_bench
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench/run.log 2>&1
 tail -2 $R/gpurun_out/prof_bench/run.log

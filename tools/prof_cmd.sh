@@ -1,6 +1,7 @@
 # usage: bash tools/prof_cmd.sh <tag> <python script> [args...]   -- rocprofv3 kernel trace + stats into gpurun_out/prof_<tag>
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 TAG=$1; shift
 mkdir -p $R/gpurun_out/prof_$TAG
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o $TAG --output-format csv -- python3 "$@" > $R/gpurun_out/prof_$TAG/run.log 2>&1

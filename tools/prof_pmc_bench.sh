@@ -1,6 +1,7 @@
 # PMC counters for the phase kernels of the bench workload (separate passes, kernel-trace only)
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 O=$R/gpurun_out/prof_pmc
 mkdir -p $O
 run() { tag=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $O/$tag -o $tag --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/$tag.log 2>&1; }

@@ -1,6 +1,7 @@
 # usage: bash tools/prof_pmc_cmd.sh <tag> <kernel-substring> <python script> [args...]  -- SQ counters per kernel (separate passes)
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 TAG=$1; KEY=$2; shift; shift
 O=$R/gpurun_out/pmc_$TAG
 mkdir -p $O

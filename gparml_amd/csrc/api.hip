@@ -131,7 +131,7 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   const int Tb = mt * dt;
   const int Sb = std::max(1, std::min(512 / std::max(1, Tb), total_chunks));
   c->part_doubles = (size_t)std::max((long)(S + 16) * c->n_tiles, (long)(Sb + 16) * Tb) * TILE * TILE;
-  if (c->part_doubles < (size_t)600 * TILE * TILE) c->part_doubles = (size_t)600 * TILE * TILE;
+  if (c->part_doubles < (size_t)1100 * TILE * TILE) c->part_doubles = (size_t)1100 * TILE * TILE;   // p1v2: up to 1024 partial tiles
   A(&c->part, c->part_doubles);
   c->kl_blocks = blocks_for(Np);
   A(&c->klpart, (size_t)c->kl_blocks + 8192);
@@ -174,6 +174,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (c->tiles64) (void)hipFree(c->tiles64);
   if (c->bmap) (void)hipFree(c->bmap);
   if (c->staging) (void)hipFree(c->staging);
+  gp::p1v2_free(c);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
   return GP_OK;

@@ -82,6 +82,7 @@ struct gp_ctx {
   size_t part_doubles = 0;
   int* tiles = nullptr;       // phase-1 tile table (int2)
   int n_tiles = 0, p1_slices = 0, p1_cps = 0;
+  void* p1plan = nullptr;     // regime-A phase-1 plan (job and output tables of p1v2.hip), built on first use
   int* bmap = nullptr;        // phase-1 block -> (slice, tile type) placement table
   int bmap_T = -1, bmap_S = -1, bmap_blocks = 0;
   double* klpart = nullptr;   // [blocks] partial KL sums
@@ -162,6 +163,10 @@ int run_upload_y(gp_ctx* c, const double* dY);
 int run_prep_and_generate(gp_ctx* c);
 int run_phase1(gp_ctx* c);
 int run_phase2(gp_ctx* c);
+// p1v2.hip (regime A phase 1 without wasted tile slots)
+bool p1v2_applicable(const gp_ctx* c);
+int run_phase1_v2(gp_ctx* c);
+void p1v2_free(gp_ctx* c);
 // psi2.hip (regime B)
 int ensure_regime_b_buffers(gp_ctx* c);
 int run_generate_b(gp_ctx* c);

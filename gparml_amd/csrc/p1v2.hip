@@ -1,0 +1,342 @@
+// Phase-1 statistics for fixed embeddings (regime A), second decomposition:  [Psi2 | C] = K^T [K | Y]  with NO wasted tile slots.
+//
+// p1_kernel8 runs one workgroup per 128x128 output tile and n-slice: MT(MT+1)/2 Psi2 tiles + MT C tiles.  A diagonal tile needs only
+// its upper triangle (144 of 256 MFMA blocks of 16x4) and a C tile only D of its 128 columns, but every workgroup of a slice streams
+// the slice in lock step, so the lighter tiles finish no sooner: at M = 512, D = 100 the launch pays 14 tile slots for 11.4 tiles of
+// work.  Here a slice is covered by two kinds of jobs:
+//   F  (i < j)  off-diagonal Psi2 tile: operands K[:, tile i], K[:, tile j]                      256 blocks per k-step
+//   G  (i)      diagonal tile i (upper triangle) AND the C row-tile i: operands K[:, tile i] (used as both the row and the column
+//               operand) and Y[:, 0:4 NBY]                                                      144 + 8 NBY blocks per k-step
+// and the two kinds get DIFFERENT slice lengths, inversely proportional to their work, so every workgroup of the launch runs equally
+// long: S_F * w_F = S_G * w_G.  All F jobs of an F-slice sit on one XCD and stream it in lock step (the slice's rows come from HBM once
+// per XCD), likewise the G jobs of a G-slice.  M = 512, D = 100: 44 F-slices x 6 + 60 G-slices x 4 = 504 workgroups, 11.4 tile units.
+// Inside a G job the eight waves pair the 16-row groups (p, 7 - p): the pair's Psi2 blocks (32 - 4p) + (4 + 4p) = 36 and its C blocks
+// 2 NBY are the same for every p, one wave takes the Psi2 blocks + the first NBY - 18 C blocks of row group p, the other the rest.
+#include "gp_common.h"
+#include <algorithm>
+#include <vector>
+
+namespace gp {
+
+struct P1Job { int kind; int acol; int bcol; int c0; int c1; int out; int pad0; int pad1; };   // kind: -1 idle, 0 F, 1 G
+struct P1v2Args { const double* Kaug; long ld; const P1Job* jobs; double* part; };
+
+template <int I> struct PIC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void pfor(F&& f) {
+  if constexpr (B < E) { f(PIC<B>{}); pfor<B + 1, E>(f); }
+}
+
+using LdsTiles = double[2][2][TILE_LDS_DOUBLES];
+
+// both operand tiles of one k-chunk: 16 LDS-DMA instructions per tile, two per wave (FREE_CONTIG rows of 128 doubles)
+__device__ __forceinline__ void p1v2_dma(LdsTiles& lds, int buf, const double* a, const double* b, long ld, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 2 + i;
+    glds16(a + (long)row * ld + 2 * lane, lds[buf][0] + row * LDS_RC);
+    glds16(b + (long)row * ld + 2 * lane, lds[buf][1] + row * LDS_RC);
+  }
+}
+
+// ---- F job: a full 128x128 tile, wave = 64 rows x 32 columns (the p1_kernel8 loop)
+__device__ __forceinline__ void p1v2_full(const P1v2Args& p, const P1Job& jb, LdsTiles& lds, int wave, int lane) {
+  const int quad = wave & 3, half = wave >> 2;
+  const int wrow0 = (quad >> 1) * WT, wcol0 = (quad & 1) * WT + 32 * half;
+  const double* Ab = p.Kaug + jb.acol + (long)jb.c0 * KC * p.ld;
+  const double* Bb = p.Kaug + jb.bcol + (long)jb.c0 * KC * p.ld;
+  const long step = (long)KC * p.ld;
+  const int nc = jb.c1 - jb.c0;
+  double acc[4][8];
+#pragma unroll
+  for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[ar][j] = 0.0;
+  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
+  const int aofs = lk * LDS_RC + wrow0 + lr, bofs = lk * LDS_RC + wcol0 + lj;
+  p1v2_dma(lds, 0, Ab, Bb, p.ld, wave, lane);
+  dma_wait();
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nc) p1v2_dma(lds, cur ^ 1, Ab + (long)(c + 1) * step, Bb + (long)(c + 1) * step, p.ld, wave, lane);
+    const unsigned aA = lds_byte_addr(lds[cur][0]) + 8u * (unsigned)aofs;
+    const unsigned aB = lds_byte_addr(lds[cur][1]) + 8u * (unsigned)bofs;
+    pfor<0, KC / 4>([&](auto k4c) {
+      constexpr int k4 = decltype(k4c)::value;
+      double a[4], b[8];
+      pfor<0, 4>([&](auto ic) { constexpr int ar = decltype(ic)::value; a[ar] = ds_read64<k4 * 4 * LDS_RC * 8 + 128 * ar>(aA); });
+      pfor<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<k4 * 4 * LDS_RC * 8 + 32 * j>(aB); });
+      pfor<0, 8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        lgkm_wait<7 - j>();
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) mfma444_acc(acc[ar][j], a[ar], b[j]);
+      });
+    });
+    dma_wait();
+    __syncthreads();
+  }
+  mfma_drain(acc[3][7]);
+#pragma unroll
+  for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);
+  double* out = p.part + (long)jb.out * (TILE * TILE);
+#pragma unroll
+  for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[(wrow0 + acc_row(ar, lane)) * TILE + wcol0 + acc_col(j, lane)] = acc[ar][j];
+}
+
+// ---- G job, wave (P, H): 16-row groups A1 = P and A2 = 7 - P of diagonal tile i.
+//   H = 0: Psi2 blocks (A1, b >= 4 A1), (A2, b >= 4 A2) and C blocks (A1, y < Y0)        36 + Y0 accumulators
+//   H = 1: C blocks (A1, y >= Y0) and (A2, all y)                                        2 NBY - Y0 accumulators
+// Y0 = NBY - 18 balances the two (NBY >= 18); operands are read in groups of at most eight 4-column groups.
+template <int P, int H, int NBY>
+__device__ __forceinline__ void p1v2_diag(const P1v2Args& p, const P1Job& jb, LdsTiles& lds, int wave, int lane) {
+  constexpr int A1 = P, A2 = 7 - P;
+  constexpr int B1 = 4 * A1, B2 = 4 * A2;                 // first column group of the two row groups' upper-triangle parts (B2 >= B1)
+  constexpr int Y0 = NBY > 18 ? NBY - 18 : 0;
+  constexpr int N1 = H == 0 ? 32 - B1 : NBY - Y0;         // accumulators of row group A1
+  constexpr int N2 = H == 0 ? 32 - B2 : NBY;              // accumulators of row group A2
+  constexpr int N3 = H == 0 ? (Y0 > 0 ? Y0 : 1) : 1;      // H = 0: C blocks (A1, y < Y0)
+  double acc1[N1 > 0 ? N1 : 1], acc2[N2], acc3[N3];
+#pragma unroll
+  for (int i = 0; i < (N1 > 0 ? N1 : 1); ++i) acc1[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < N2; ++i) acc2[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < N3; ++i) acc3[i] = 0.0;
+  const double* Ab = p.Kaug + jb.acol + (long)jb.c0 * KC * p.ld;
+  const double* Bb = p.Kaug + jb.bcol + (long)jb.c0 * KC * p.ld;
+  const long step = (long)KC * p.ld;
+  const int nc = jb.c1 - jb.c0;
+  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
+  p1v2_dma(lds, 0, Ab, Bb, p.ld, wave, lane);
+  dma_wait();
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nc) p1v2_dma(lds, cur ^ 1, Ab + (long)(c + 1) * step, Bb + (long)(c + 1) * step, p.ld, wave, lane);
+    const unsigned rowop = lds_byte_addr(lds[cur][0]) + 8u * (unsigned)(lk * LDS_RC + lr);   // A-operand view of the K tile (16 rows of the output)
+    const unsigned colK = lds_byte_addr(lds[cur][0]) + 8u * (unsigned)(lk * LDS_RC + lj);    // B-operand view of the SAME tile (4 output columns)
+    const unsigned colY = lds_byte_addr(lds[cur][1]) + 8u * (unsigned)(lk * LDS_RC + lj);    // B-operand view of the Y tile
+    pfor<0, KC / 4>([&](auto k4c) {
+      constexpr int k4 = decltype(k4c)::value;
+      constexpr int KO = k4 * 4 * LDS_RC * 8;
+      const double a1 = ds_read64<KO + 128 * A1>(rowop);
+      const double a2 = ds_read64<KO + 128 * A2>(rowop);
+      if constexpr (H == 0) {
+        pfor<0, (32 - B1 + 7) / 8>([&](auto gc) {
+          constexpr int b0 = B1 + 8 * decltype(gc)::value;
+          constexpr int nb = (32 - b0) < 8 ? (32 - b0) : 8;
+          double b[nb];
+          pfor<0, nb>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<KO + 32 * (b0 + j)>(colK); });
+          pfor<0, nb>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            lgkm_wait<nb - 1 - j>();
+            mfma444_acc(acc1[b0 + j - B1], a1, b[j]);
+            if constexpr (b0 + j >= B2) mfma444_acc(acc2[b0 + j - B2], a2, b[j]);
+          });
+        });
+        if constexpr (Y0 > 0) {
+          pfor<0, (Y0 + 7) / 8>([&](auto gc) {
+            constexpr int y0 = 8 * decltype(gc)::value;
+            constexpr int ny = (Y0 - y0) < 8 ? (Y0 - y0) : 8;
+            double y[ny];
+            pfor<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; y[j] = ds_read64<KO + 32 * (y0 + j)>(colY); });
+            pfor<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; lgkm_wait<ny - 1 - j>(); mfma444_acc(acc3[y0 + j], a1, y[j]); });
+          });
+        }
+      } else {
+        pfor<0, (NBY + 7) / 8>([&](auto gc) {
+          constexpr int y0 = 8 * decltype(gc)::value;
+          constexpr int ny = (NBY - y0) < 8 ? (NBY - y0) : 8;
+          double y[ny];
+          pfor<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; y[j] = ds_read64<KO + 32 * (y0 + j)>(colY); });
+          pfor<0, ny>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            lgkm_wait<ny - 1 - j>();
+            mfma444_acc(acc2[y0 + j], a2, y[j]);
+            if constexpr (y0 + j >= Y0) mfma444_acc(acc1[y0 + j - Y0], a1, y[j]);
+          });
+        });
+      }
+    });
+    dma_wait();
+    __syncthreads();
+  }
+  mfma_drain(acc2[N2 - 1]);
+  acc_fence<(N1 > 0 ? N1 : 1)>(acc1);
+  acc_fence<N2>(acc2);
+  acc_fence<N3>(acc3);
+  // partial tiles: jb.out = the diagonal Psi2 tile (upper blocks only), jb.out + 1 = the C tile (columns < 4 NBY)
+  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  double* t0 = p.part + (long)jb.out * (TILE * TILE);
+  double* t1 = t0 + TILE * TILE;
+  if constexpr (H == 0) {
+#pragma unroll
+    for (int i = 0; i < N1; ++i) t0[(16 * A1 + srow) * TILE + 4 * (B1 + i) + lj] = acc1[i];
+#pragma unroll
+    for (int i = 0; i < N2; ++i) t0[(16 * A2 + srow) * TILE + 4 * (B2 + i) + lj] = acc2[i];
+    if constexpr (Y0 > 0) {
+#pragma unroll
+      for (int i = 0; i < Y0; ++i) t1[(16 * A1 + srow) * TILE + 4 * i + lj] = acc3[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N1; ++i) t1[(16 * A1 + srow) * TILE + 4 * (Y0 + i) + lj] = acc1[i];
+#pragma unroll
+    for (int i = 0; i < N2; ++i) t1[(16 * A2 + srow) * TILE + 4 * i + lj] = acc2[i];
+  }
+}
+
+template <int NBY>
+__global__ void __launch_bounds__(512, 4) p1v2_kernel(P1v2Args p) {
+  const P1Job jb = p.jobs[blockIdx.x];
+  if (jb.kind < 0) return;
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (jb.kind == 0) { p1v2_full(p, jb, lds, wave, lane); return; }
+  switch (wave) {      // (P, H) = (wave & 3, wave >> 2): a SIMD hosts one wave of each half
+    case 0: p1v2_diag<0, 0, NBY>(p, jb, lds, wave, lane); break;
+    case 1: p1v2_diag<1, 0, NBY>(p, jb, lds, wave, lane); break;
+    case 2: p1v2_diag<2, 0, NBY>(p, jb, lds, wave, lane); break;
+    case 3: p1v2_diag<3, 0, NBY>(p, jb, lds, wave, lane); break;
+    case 4: p1v2_diag<0, 1, NBY>(p, jb, lds, wave, lane); break;
+    case 5: p1v2_diag<1, 1, NBY>(p, jb, lds, wave, lane); break;
+    case 6: p1v2_diag<2, 1, NBY>(p, jb, lds, wave, lane); break;
+    default: p1v2_diag<3, 1, NBY>(p, jb, lds, wave, lane); break;
+  }
+}
+
+// sums the slices of every output tile in a fixed order; writes Psi2 (both triangles) and C into the packed statistics buffer.
+//   out tile descriptor: kind 0 F (ti < tj), 1 diagonal tile ti (valid where col >= row), 2 C row-tile ti (valid columns < ncols)
+struct P1Out { int kind, ti, tj, first, nslices, stride, ncols, pad; };
+__global__ void __launch_bounds__(256) p1v2_reduce_kernel(const double* __restrict__ part, const P1Out* __restrict__ outs,
+                                                          double* __restrict__ Psi2, double* __restrict__ C, int Mp, int Dp) {
+  const P1Out o = outs[blockIdx.y];
+  const int e = blockIdx.x * 256 + threadIdx.x;   // element of the 128x128 tile
+  const int r = e >> 7, c = e & 127;
+  if (o.kind == 1 && c < r) return;               // filled by its mirror image
+  if (o.kind == 2 && c >= Dp) return;
+  double s = 0.0;
+  if (o.kind != 2 || c < o.ncols)
+    for (int sl = 0; sl < o.nslices; ++sl) s += part[((long)o.first + (long)sl * o.stride) * (TILE * TILE) + e];
+  if (o.kind == 2) {
+    C[((long)o.ti * TILE + r) * Dp + c] = s;
+  } else {
+    const long R = (long)o.ti * TILE + r, Cc = (long)o.tj * TILE + c;
+    Psi2[R * Mp + Cc] = s;
+    Psi2[Cc * Mp + R] = s;
+  }
+}
+
+// ---- host: plan (cached per context), launch
+struct P1Plan {
+  int Mp = -1, Dp = -1, D = -1; long Np = -1;
+  int nby = 0, blocks = 0, nouts = 0;
+  P1Job* jobs = nullptr; P1Out* outs = nullptr;
+};
+
+static bool pack_slices(int nF, int SF, int nG, int SG, std::vector<int>& xcd_of_F, std::vector<int>& xcd_of_G) {
+  int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  xcd_of_F.assign(SF, -1); xcd_of_G.assign(SG, -1);
+  for (int s = 0; s < SF; ++s) {
+    int best = -1;
+    for (int x = 0; x < 8; ++x) if (fill[x] + nF <= 64 && (best < 0 || fill[x] < fill[best])) best = x;
+    if (best < 0) return false;
+    xcd_of_F[s] = best; fill[best] += nF;
+  }
+  for (int s = 0; s < SG; ++s) {
+    int best = -1;
+    for (int x = 0; x < 8; ++x) if (fill[x] + nG <= 64 && (best < 0 || fill[x] < fill[best])) best = x;
+    if (best < 0) return false;
+    xcd_of_G[s] = best; fill[best] += nG;
+  }
+  return true;
+}
+
+bool p1v2_applicable(const gp_ctx* c) { return c->regime_A && c->D <= 104 && c->Mp / TILE <= 11; }
+
+int run_phase1_v2(gp_ctx* c) {
+  const int MT = c->Mp / TILE;
+  const int nby = c->D <= 32 ? 8 : 26;
+  const int nF = MT * (MT - 1) / 2, nG = MT;
+  const int wF = 256, wG = 144 + 8 * nby;   // MFMA blocks per k-step; a sweep of the effective G weight (330..440) is flat around the nominal value
+  const int total_chunks = (int)(c->Np / KC);
+  P1Plan* pl = static_cast<P1Plan*>(c->p1plan);
+  if (!pl) { pl = new P1Plan(); c->p1plan = pl; }
+  if (pl->Mp != c->Mp || pl->Dp != c->Dp || pl->D != c->D || pl->Np != c->Np) {
+    // slice counts: S_F w_F = S_G w_G (equal running time), as many workgroups as fit 8 XCDs x 64 resident slots with every
+    // slice's jobs on one XCD
+    int SF = 0, SG = 0;
+    std::vector<int> xF, xG;
+    for (int sg = std::min(std::min(512 / std::max(nG, 1), total_chunks), 1024 / (2 * nG + nF)); sg >= 1; --sg) {
+      int sf = nF > 0 ? std::max(1, (int)((double)sg * wF / wG + 0.5)) : 0;
+      sf = std::min(sf, total_chunks);
+      if ((long)nF * sf + (long)nG * sg > 512) continue;
+      if (pack_slices(nF, sf, nG, sg, xF, xG)) { SF = sf; SG = sg; break; }
+    }
+    if (SG == 0) return fail(c, GP_ERR_UNSUPPORTED, "phase-1 planner found no placement (M = %d)", c->M);
+    // jobs in block order: block b runs on XCD b % 8; XCD x's j-th slot is block j * 8 + x
+    std::vector<std::vector<P1Job>> per_xcd(8);
+    std::vector<P1Out> outs;
+    int next_part = 0;
+    std::vector<int> tF;                                   // F tiles (i < j)
+    for (int i = 0; i < MT; ++i) for (int j = i + 1; j < MT; ++j) { tF.push_back(i); tF.push_back(j); }
+    const int baseF = next_part; next_part += SF * nF;
+    const int baseG = next_part; next_part += SG * nG * 2;
+    if ((size_t)next_part * TILE * TILE > c->part_doubles) return fail(c, GP_ERR_UNSUPPORTED, "phase-1 partial buffer too small");
+    for (int s = 0; s < SF; ++s) {
+      const int c0 = (int)((long)s * total_chunks / SF), c1 = (int)((long)(s + 1) * total_chunks / SF);
+      for (int t = 0; t < nF; ++t)
+        per_xcd[xF[s]].push_back(P1Job{0, tF[2 * t] * TILE, tF[2 * t + 1] * TILE, c0, c1, baseF + s * nF + t, 0, 0});
+    }
+    for (int s = 0; s < SG; ++s) {
+      const int c0 = (int)((long)s * total_chunks / SG), c1 = (int)((long)(s + 1) * total_chunks / SG);
+      for (int i = 0; i < nG; ++i) per_xcd[xG[s]].push_back(P1Job{1, i * TILE, c->Mp, c0, c1, baseG + (s * nG + i) * 2, 0, 0});
+    }
+    size_t depth = 0;
+    for (auto& v : per_xcd) depth = std::max(depth, v.size());
+    std::vector<P1Job> jobs(depth * 8, P1Job{-1, 0, 0, 0, 0, 0, 0, 0});
+    for (int x = 0; x < 8; ++x) for (size_t j = 0; j < per_xcd[x].size(); ++j) jobs[j * 8 + x] = per_xcd[x][j];
+    for (int t = 0; t < nF; ++t) outs.push_back(P1Out{0, tF[2 * t], tF[2 * t + 1], baseF + t, SF, nF, TILE, 0});
+    for (int i = 0; i < nG; ++i) {
+      outs.push_back(P1Out{1, i, i, baseG + i * 2, SG, nG * 2, TILE, 0});
+      outs.push_back(P1Out{2, i, 0, baseG + i * 2 + 1, SG, nG * 2, 4 * nby, 0});
+    }
+    if (pl->jobs) (void)hipFree(pl->jobs);
+    if (pl->outs) (void)hipFree(pl->outs);
+    pl->jobs = nullptr; pl->outs = nullptr;
+    GP_HIP(c, hipMalloc((void**)&pl->jobs, jobs.size() * sizeof(P1Job)));
+    GP_HIP(c, hipMalloc((void**)&pl->outs, outs.size() * sizeof(P1Out)));
+    GP_HIP(c, hipMemcpyAsync(pl->jobs, jobs.data(), jobs.size() * sizeof(P1Job), hipMemcpyHostToDevice, c->stream));
+    GP_HIP(c, hipMemcpyAsync(pl->outs, outs.data(), outs.size() * sizeof(P1Out), hipMemcpyHostToDevice, c->stream));
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+    pl->Mp = c->Mp; pl->Dp = c->Dp; pl->D = c->D; pl->Np = c->Np; pl->nby = nby;
+    pl->blocks = (int)jobs.size(); pl->nouts = (int)outs.size();
+  }
+  P1v2Args p;
+  p.Kaug = c->Kaug; p.ld = c->LDK; p.jobs = pl->jobs; p.part = c->part;
+  (void)hipEventRecord(c->ev[10], c->stream);
+  if (pl->nby == 8) hipLaunchKernelGGL((p1v2_kernel<8>), dim3(pl->blocks), dim3(512), 0, c->stream, p);
+  else hipLaunchKernelGGL((p1v2_kernel<26>), dim3(pl->blocks), dim3(512), 0, c->stream, p);
+  (void)hipEventRecord(c->ev[11], c->stream);
+  GP_HIP(c, hipGetLastError());
+  double* Psi2 = c->stats;
+  double* C = c->stats + (long)c->Mp * c->Mp;
+  hipLaunchKernelGGL(p1v2_reduce_kernel, dim3(TILE * TILE / 256, pl->nouts), dim3(256), 0, c->stream, c->part, pl->outs, Psi2, C, c->Mp, c->Dp);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+void p1v2_free(gp_ctx* c) {
+  P1Plan* pl = static_cast<P1Plan*>(c->p1plan);
+  if (!pl) return;
+  if (pl->jobs) (void)hipFree(pl->jobs);
+  if (pl->outs) (void)hipFree(pl->outs);
+  delete pl;
+  c->p1plan = nullptr;
+}
+
+}  // namespace gp

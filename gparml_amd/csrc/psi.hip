@@ -354,6 +354,15 @@ int run_prep_and_generate(gp_ctx* c) {
 }
 
 int run_phase1(gp_ctx* c) {
+  if (p1v2_applicable(c)) {
+    // fixed embeddings / sparse GP: the decomposition without wasted tile slots (p1v2.hip)
+    int rc = run_phase1_v2(c);
+    if (rc != GP_OK) return rc;
+    hipLaunchKernelGGL(p1_scalars_kernel, dim3(1), dim3(256), 0, c->stream, c->klpart, c->kl_blocks, c->sumYY, c->sf2, (double)c->N,
+                       1, c->stats + (long)c->Mp * c->Mp + (long)c->Mp * c->Dp);
+    GP_HIP(c, hipGetLastError());
+    return GP_OK;
+  }
   const int mt = c->Mp / TILE;
   // regime A: Psi2 = Psi1^T Psi1 and C tiles; regime B: only the C tiles here (Psi2 comes from the pair kernel)
   const int first = c->regime_A ? 0 : c->n_tiles - mt * (c->Dp / TILE);

@@ -74,112 +74,112 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
   }
 }
 
-// Eight-wave variant for the latency-bound products of the global step (a handful of tiles, K <= 1024): the same 128x128 tile, LDS
-// image and DMA traffic, but each 64x64 quadrant is shared by two waves (64 rows x 32 columns each, as in p1_kernel8), so the serial
-// MFMA time of a tile halves -- with one or two workgroups per CU in flight the four-wave kernel spends 1.7 us per k-chunk on a
-// single wave per SIMD.  Operand reads are explicit ds_read_b64 (mma_f64.h).
+// Small-tile variant for the latency-bound products of the global step (M x M x {M, D, 128} with M a few hundred).  One CU
+// delivers 0.29 TFLOP/s of FP64 MFMA, so a 128 x 128 x 128 tile product takes 15 us on the CU that owns it whatever the
+// kernel does; those products have 1 to 16 such tiles and left 94 % of the chip idle (eight-wave 128-tile kernel: 21 us per
+// launch).  Here a workgroup owns a 32 x 32 output tile (four waves, 16 x 16 each: one A and four B operand registers, four
+// accumulators) and walks K in chunks of 128 staged through LDS from registers (one global round trip per chunk, the next
+// chunk's loads in flight during the MFMAs), so a 128^3 product is sixteen workgroups of 0.9 us MFMA time each.
+//   LDS image of an operand chunk: K_CONTIG  [32 free][128 k], row stride 130  (16 rows x {k, k+1} cover 32 distinct 8-byte slots)
+//                                  FREE_CONTIG [128 k][32 free], row stride 48 (k and k+1 sit 16 slots apart)
+// Operand reads are explicit ds_read_b64 with counted lgkmcnt waits (mma_f64.h).
 template <int I> struct GIC { static constexpr int value = I; };
 template <int B, int E, typename F>
 __device__ __forceinline__ void gfor(F&& f) {
   if constexpr (B < E) { f(GIC<B>{}); gfor<B + 1, E>(f); }
 }
 
-constexpr int G8_STAGES = 4;   // LDS ring of the eight-wave kernel: 4 x (A tile + B tile) = 144 KB, one workgroup per CU
+constexpr int ST = 32;     // workgroup tile of the small kernel
+constexpr int SKC = 128;   // its k-chunk
+template <Layout L> struct SmallImg {
+  static constexpr int LD = (L == K_CONTIG) ? SKC + 2 : ST + 16;
+  static constexpr int DOUBLES = (L == K_CONTIG) ? ST * LD : SKC * LD;
+};
+
+// this thread's 8 x 16 bytes of a [32 x 128] operand chunk; kleft = K - k0 (a multiple of 16; elements beyond it read as zero)
+template <Layout L>
+__device__ __forceinline__ void small_load(const double* __restrict__ src, long ld, int kleft, int tid, double2 (&r)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + 256 * i;
+    const int k = (L == K_CONTIG) ? 2 * (e & 63) : (e >> 4);
+    const double* g = (L == K_CONTIG) ? src + (long)(e >> 6) * ld + k : src + (long)k * ld + 2 * (e & 15);
+    r[i] = (k < kleft) ? *reinterpret_cast<const double2*>(g) : make_double2(0.0, 0.0);
+  }
+}
+template <Layout L>
+__device__ __forceinline__ void small_store(double* img, int tid, const double2 (&r)[8]) {
+  constexpr int LD = SmallImg<L>::LD;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + 256 * i;
+    double* d = (L == K_CONTIG) ? img + (e >> 6) * LD + 2 * (e & 63) : img + (e >> 4) * LD + 2 * (e & 15);
+    *reinterpret_cast<double2*>(d) = r[i];
+  }
+}
 
 template <Layout LA, Layout LB>
-__global__ void __launch_bounds__(512, 2) gemm128_kernel8(GemmP p) {
-  const int bx = blockIdx.x, by = blockIdx.y;
-  const int bz = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
-  if (p.tri == 1 && bx > by) return;
+__global__ void __launch_bounds__(256, 1) gemm32_kernel(GemmP p) {
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.tri == 1 && bx > by) return;     // 32-tile granularity: every tile that touches the lower triangle is computed
   if (p.tri == 2 && bx < by) return;
-  __shared__ __attribute__((aligned(16))) double lds[G8_STAGES][2][TILE_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sA[SmallImg<LA>::DOUBLES];
+  __shared__ __attribute__((aligned(16))) double sB[SmallImg<LB>::DOUBLES];
+  constexpr int LDA = SmallImg<LA>::LD, LDB = SmallImg<LB>::LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int quad = wave & 3, half = wave >> 2;
-  const int wrow0 = (quad >> 1) * WT, wcol0 = (quad & 1) * WT + 32 * half;
+  const int wr = 16 * (wave >> 1), wc = 16 * (wave & 1);
+  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
   const int bi = bz % p.inner, bo = bz / p.inner;
   const double* A = p.A + (long)bi * p.sA + (long)bo * p.oA;
   const double* B = p.B + (long)bi * p.sB + (long)bo * p.oB;
   double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
-  const long row0 = (long)by * TILE, col0 = (long)bx * TILE;
-  const int nc = p.K / KC / p.splits;          // chunks of this split
-  const long k0 = (long)sp * nc * KC;
-  const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda + k0 : A + row0 + k0 * p.lda;
-  const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb + k0 : B + col0 + k0 * p.ldb;
-  const long a_step = (LA == K_CONTIG) ? KC : (long)KC * p.lda;
-  const long b_step = (LB == K_CONTIG) ? KC : (long)KC * p.ldb;
-  double acc[4][8];
-#pragma unroll
-  for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[ar][j] = 0.0;
-  const LaneOfs ofs = lane_offsets<LA, LB>(wrow0, wcol0, lane);
-  // 16 DMA instructions per operand tile, two per wave: FOUR per wave and chunk
-  auto dma = [&](int c) {
-    const int buf = c % G8_STAGES;
-    const double* a = Ab + (long)c * a_step;
-    const double* b = Bb + (long)c * b_step;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int I = wave * 2 + i;
-      if (LA == FREE_CONTIG) glds16(a + (long)I * p.lda + 2 * lane, lds[buf][0] + I * LDS_RC);
-      else { const int row = swap03(I * 8 + (lane >> 3)); glds16(a + (long)row * p.lda + 2 * ((lane & 7) ^ (row & 7)), lds[buf][0] + I * 8 * KC); }
-      if (LB == FREE_CONTIG) glds16(b + (long)I * p.ldb + 2 * lane, lds[buf][1] + I * LDS_RC);
-      else { const int row = swap03(I * 8 + (lane >> 3)); glds16(b + (long)row * p.ldb + 2 * ((lane & 7) ^ (row & 7)), lds[buf][1] + I * 8 * KC); }
-    }
-  };
-  // The products of the global step are latency-bound (one workgroup per tile, a k-chunk computes in 0.85 us but takes ~2 us to
-  // arrive): up to three chunks stay in flight.  Waits are counted (vmcnt(4 x chunks still allowed in flight)) and the barrier is
-  // the raw s_barrier -- __syncthreads() would drain the DMA queue (its fence waits for vmcnt(0) while an LDS-DMA is pending).
-  for (int c = 0; c < G8_STAGES - 1 && c < nc; ++c) dma(c);
+  const long row0 = (long)by * ST, col0 = (long)bx * ST;
+  const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda : A + row0;
+  const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb : B + col0;
+  const long a_step = (LA == K_CONTIG) ? SKC : (long)SKC * p.lda;
+  const long b_step = (LB == K_CONTIG) ? SKC : (long)SKC * p.ldb;
+  const int nc = (p.K + SKC - 1) / SKC;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const unsigned aA = lds_byte_addr(sA) + 8u * (unsigned)(LA == K_CONTIG ? (wr + lr) * LDA + lk : lk * LDA + wr + lr);
+  const unsigned aB = lds_byte_addr(sB) + 8u * (unsigned)(LB == K_CONTIG ? (wc + lj) * LDB + lk : lk * LDB + wc + lj);
+  double2 ra[8], rb[8];
+  small_load<LA>(Ab, p.lda, p.K, tid, ra);
+  small_load<LB>(Bb, p.ldb, p.K, tid, rb);
   for (int c = 0; c < nc; ++c) {
-    const int ahead = min(G8_STAGES - 2, nc - 1 - c);          // chunks after c already issued and not needed yet
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                              // chunk c has landed for every wave; chunk c - 1 has been consumed by all
-    if (c + G8_STAGES - 1 < nc) dma(c + G8_STAGES - 1);        // into the buffer chunk c - 1 used
-    const int cur = c % G8_STAGES;
-    const unsigned sa = lds_byte_addr(lds[cur][0]), sb = lds_byte_addr(lds[cur][1]);
-    gfor<0, KC / 4>([&](auto k4c) {
-      constexpr int k4 = decltype(k4c)::value;
-      double a[4], b[8];
-      const unsigned aA = sa + 8u * (unsigned)(LA == FREE_CONTIG ? ofs.a[0] : ofs.a[k4]);
-      const unsigned aB = sb + 8u * (unsigned)(LB == FREE_CONTIG ? ofs.b[0] : ofs.b[k4 & 1]);
-      gfor<0, 4>([&](auto ic) {
-        constexpr int ar = decltype(ic)::value;
-        a[ar] = ds_read64<(LA == FREE_CONTIG ? (4 * k4 * LDS_RC + 16 * ar) : 256 * ar) * 8>(aA);
-      });
-      gfor<0, 8>([&](auto jc) {
-        constexpr int bc = decltype(jc)::value;
-        b[bc] = ds_read64<(LB == FREE_CONTIG ? (4 * k4 * LDS_RC + 4 * bc)
-                                              : ((bc & 1) * 64 + ((bc >> 1) & 1) * 16 + (bc >> 2) * 256 + (((k4 >> 1) ^ (bc & 1)) << 3))) * 8>(aB);
-      });
-      gfor<0, 8>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        lgkm_wait<7 - j>();
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar) mfma444_acc(acc[ar][j], a[ar], b[j]);
-      });
-    });
-  }
-  mfma_drain(acc[3][7]);
-#pragma unroll
-  for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);
-  if (p.splits > 1) {
-    double* w = p.ws + ((((long)bz * gridDim.y + by) * gridDim.x + bx) * p.splits + sp) * (TILE * TILE);
-#pragma unroll
-    for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-      for (int bc = 0; bc < 8; ++bc) w[(wrow0 + acc_row(ar, lane)) * TILE + wcol0 + acc_col(bc, lane)] = acc[ar][bc];
-    return;
-  }
-#pragma unroll
-  for (int ar = 0; ar < 4; ++ar)
-#pragma unroll
-    for (int bc = 0; bc < 8; ++bc) {
-      const long r = row0 + wrow0 + acc_row(ar, lane), cc = col0 + wcol0 + acc_col(bc, lane);
-      C[r * p.ldc + cc] = p.alpha * acc[ar][bc] + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
+    small_store<LA>(sA, tid, ra);
+    small_store<LB>(sB, tid, rb);
+    __syncthreads();
+    if (c + 1 < nc) {
+      small_load<LA>(Ab + (long)(c + 1) * a_step, p.lda, p.K - (c + 1) * SKC, tid, ra);
+      small_load<LB>(Bb + (long)(c + 1) * b_step, p.ldb, p.K - (c + 1) * SKC, tid, rb);
     }
+    double a[2], b[2][4];
+    auto rd = [&](auto kc, double& av, double (&bv)[4]) {
+      constexpr int k4 = decltype(kc)::value;
+      av = ds_read64<(LA == K_CONTIG ? 4 * k4 : 4 * k4 * LDA) * 8>(aA);
+      gfor<0, 4>([&](auto jc) {
+        constexpr int bc = decltype(jc)::value;
+        bv[bc] = ds_read64<(LB == K_CONTIG ? 4 * bc * LDB + 4 * k4 : 4 * k4 * LDB + 4 * bc) * 8>(aB);
+      });
+    };
+    rd(GIC<0>{}, a[0], b[0]);
+    gfor<0, SKC / 4>([&](auto kc) {
+      constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
+      if constexpr (k4 + 1 < SKC / 4) { rd(GIC<k4 + 1>{}, a[cur ^ 1], b[cur ^ 1]); lgkm_wait<5>(); }
+      else lgkm_wait<0>();
+#pragma unroll
+      for (int bc = 0; bc < 4; ++bc) mfma444_acc(acc[bc], a[cur], b[cur][bc]);
+    });
+    __syncthreads();
+  }
+  mfma_drain(acc[3]);
+  acc_fence(acc);
+  const long r = row0 + wr + 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+  for (int bc = 0; bc < 4; ++bc) {
+    const long cc = col0 + wc + 4 * bc + lj;
+    C[r * p.ldc + cc] = p.alpha * acc[bc] + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
+  }
 }
 
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int tiles_x, int tiles_y) {
@@ -203,14 +203,16 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int ti
 
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p) {
   dim3 grid(n / TILE, m / TILE, batch * p.splits), block(256);
-  if ((long)grid.x * grid.y * grid.z <= 256) {
-    // few tiles (the global step): the eight-wave kernel halves the serial time of a tile
-    dim3 b8(512);
-    if (la == K_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel8<K_CONTIG, FREE_CONTIG>), grid, b8, 0, st, p);
-    else if (la == K_CONTIG && lb == K_CONTIG) hipLaunchKernelGGL((gemm128_kernel8<K_CONTIG, K_CONTIG>), grid, b8, 0, st, p);
-    else if (la == FREE_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel8<FREE_CONTIG, FREE_CONTIG>), grid, b8, 0, st, p);
-    else hipLaunchKernelGGL((gemm128_kernel8<FREE_CONTIG, K_CONTIG>), grid, b8, 0, st, p);
-  } else if (la == K_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<K_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
+  if ((long)(n / TILE) * (m / TILE) * batch <= 256) {
+    // few tiles (the global step): 32 x 32 tiles spread the product over the chip; split-k is not needed there
+    dim3 g32(n / ST, m / ST, batch);
+    if (la == K_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm32_kernel<K_CONTIG, FREE_CONTIG>), g32, block, 0, st, p);
+    else if (la == K_CONTIG && lb == K_CONTIG) hipLaunchKernelGGL((gemm32_kernel<K_CONTIG, K_CONTIG>), g32, block, 0, st, p);
+    else if (la == FREE_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm32_kernel<FREE_CONTIG, FREE_CONTIG>), g32, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm32_kernel<FREE_CONTIG, K_CONTIG>), g32, block, 0, st, p);
+    return;
+  }
+  if (la == K_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<K_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
   else if (la == K_CONTIG && lb == K_CONTIG) hipLaunchKernelGGL((gemm128_kernel<K_CONTIG, K_CONTIG>), grid, block, 0, st, p);
   else if (la == FREE_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, FREE_CONTIG>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((gemm128_kernel<FREE_CONTIG, K_CONTIG>), grid, block, 0, st, p);

@@ -6,157 +6,13 @@
 // All matrices are padded to multiples of 128 with an identity block, which leaves log-determinants, inverses
 // and every trace unchanged.
 #include "gp_common.h"
+#include "potrf128.h"
 #include <cmath>
 
 namespace gp {
 
 constexpr int kSplitK = 8;   // split-k factor of the M x M x M products of the global step (latency-bound: 16 tiles alone fill 6 % of the chip)
 
-constexpr int NB = 128;  // panel width = GEMM tile
-
-// ---------------------------------------------------------------------------------------------- diagonal panels
-// Cholesky of the 128x128 diagonal block j of each matrix in the batch.  1024 threads; thread (ti,tj) keeps the 4x4
-// sub-block (rows 4ti.., cols 4tj..) in registers.  For every 4-column panel: the owner of the diagonal 4x4 factors it,
-// the threads below it solve their 4x4 against it, then everybody applies the rank-4 update from the panel staged in
-// LDS -- two barriers per panel, 64 in total (the element-wise variant needed 256 and was 6x slower).
-__global__ void __launch_bounds__(1024) potrf_diag_kernel(double* A, long ld, long bstride, int j, double* fail) {
-  __shared__ double panel2[2][NB][5];   // double-buffered by panel parity: step 3 of panel b overlaps step 1 of panel b+1
-  __shared__ double Lbb[4][4];
-  const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
-  double* blk = A + (long)blockIdx.x * bstride + ((long)j * NB) * ld + (long)j * NB;
-  double a[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[r][c] = (ti >= tj) ? blk[(long)(4 * ti + r) * ld + 4 * tj + c] : 0.0;
-  double bad = 0.0;   // 1: negative (or NaN) pivot -- indefinite; 2: pivot exactly zero -- singular (numpy.linalg.inv raises for that one)
-  for (int bj = 0; bj < 32; ++bj) {
-    double (*panel)[5] = panel2[bj & 1];
-    if (ti == bj && tj == bj) {
-      // unblocked 4x4 Cholesky in registers (lower); reciprocals of the diagonal go to LDS so that the solves below
-      // multiply instead of divide (an f64 division is ~30 instructions on the critical path of every panel)
-      double inv[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double d2 = a[c][c];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < c) d2 -= a[c][k] * a[c][k];
-        if (!(d2 > 0.0) || !(d2 < 1e300)) { bad = fmax(bad, d2 == 0.0 ? 2.0 : 1.0); d2 = 1.0; }
-        const double d = sqrt(d2);
-        inv[c] = 1.0 / d;
-        a[c][c] = d;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r > c) {
-            double v = a[r][c];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (k < c) v -= a[r][k] * a[c][k];
-            a[r][c] = v * inv[c];
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double v = (c <= r) ? a[r][c] : 0.0;
-          a[r][c] = v;
-          Lbb[r][c] = (c == r) ? inv[c] : v;      // diagonal slot holds 1 / L_cc
-          panel[4 * ti + r][c] = v;
-        }
-      if (bad != 0.0) fail[blockIdx.x] = fmax(fail[blockIdx.x], bad);
-    }
-    __syncthreads();
-    if (tj == bj && ti > bj) {
-      // X = A * Lbb^-T  (row by row forward substitution)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double v = a[r][c];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < c) v -= a[r][k] * Lbb[c][k];
-          a[r][c] = v * Lbb[c][c];                 // Lbb diagonal = reciprocal
-          panel[4 * ti + r][c] = a[r][c];
-        }
-      }
-    }
-    __syncthreads();
-    if (tj > bj && ti >= tj) {
-      double pr[4][4], pc[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { pr[r][k] = panel[4 * ti + r][k]; pc[r][k] = panel[4 * tj + r][k]; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) a[r][c] = fma(-pr[r][k], pc[c][k], a[r][c]);
-    }
-    // the next panel's writes to Lbb / panel happen after the next barrier pair: no extra barrier needed here
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int R = 4 * ti + r, C = 4 * tj + c;
-      blk[(long)R * ld + C] = (C <= R) ? a[r][c] : 0.0;
-    }
-}
-
-// inverse of the lower-triangular 128x128 diagonal block j by recursive doubling:
-//   [X11 0; X21 X22] with X21 = -X22 (L21 X11), block size 1, 2, 4, ... 64 -- 7 levels, 2 barriers each.
-__global__ void __launch_bounds__(1024) trinv_diag_kernel(const double* L, long ld, long bstride, int j, double* Linv) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* X = sm;
-  double* T = sm + NB * NB;
-  const int tid = threadIdx.x;
-  const long off = (long)blockIdx.x * bstride + ((long)j * NB) * ld + (long)j * NB;
-  for (int idx = tid; idx < NB * NB; idx += 1024) X[idx] = L[off + (long)(idx >> 7) * ld + (idx & 127)];
-  __syncthreads();
-  if (tid < NB) X[tid * NB + tid] = 1.0 / X[tid * NB + tid];
-  __syncthreads();
-  for (int ls = 0; ls < 7; ++ls) {
-    const int s = 1 << ls;
-    const int outs = 64 * s;  // (128 / 2s) pairs x s x s
-    for (int o = tid; o < outs; o += 1024) {
-      const int p = o >> (2 * ls), r = (o >> ls) & (s - 1), c = o & (s - 1);
-      const int R0 = (2 * p + 1) * s, C0 = 2 * p * s;
-      double sum = 0.0;
-      for (int k = c; k < s; ++k) sum += X[(R0 + r) * NB + C0 + k] * X[(C0 + k) * NB + C0 + c];
-      T[o] = sum;
-    }
-    __syncthreads();
-    for (int o = tid; o < outs; o += 1024) {
-      const int p = o >> (2 * ls), r = (o >> ls) & (s - 1), c = o & (s - 1);
-      const int R0 = (2 * p + 1) * s, C0 = 2 * p * s;
-      double sum = 0.0;
-      for (int k = 0; k <= r; ++k) sum += X[(R0 + r) * NB + R0 + k] * T[(p << (2 * ls)) + (k << ls) + c];
-      X[(R0 + r) * NB + C0 + c] = -sum;
-    }
-    __syncthreads();
-  }
-  for (int idx = tid; idx < NB * NB; idx += 1024) {
-    const int r = idx >> 7, c = idx & 127;
-    Linv[off + (long)r * ld + c] = (c <= r) ? X[idx] : 0.0;
-  }
-}
-
-__global__ void logdet_kernel(const double* L, long ld, long bstride, int n, double* out) {
-  __shared__ double red[256];
-  const double* Lb = L + (long)blockIdx.x * bstride;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += log(Lb[(long)i * ld + i]);
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) {
-    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * red[0];
-}
 
 __global__ void zero_kernel(double* x, long n) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] = 0.0;
@@ -169,11 +25,10 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
   const int nt = Mp / NB;
   const long ld = Mp, bs = (long)Mp * Mp;
   // a per-device attribute: set on every call (cheap) rather than once per process -- contexts may live on several GPUs
-  GP_HIP(c, hipFuncSetAttribute((const void*)trinv_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NB * NB + 4096) * 8));
+  GP_HIP(c, hipFuncSetAttribute((const void*)potrf_trinv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_DOUBLES * 8));
   hipLaunchKernelGGL(zero_kernel, dim3(1024), dim3(256), 0, st, Linv, bs * batch);
   for (int j = 0; j < nt; ++j) {
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(1024), 0, st, A, ld, bs, j, fail_flag);
-    hipLaunchKernelGGL(trinv_diag_kernel, dim3(batch), dim3(1024), (NB * NB + 4096) * 8, st, A, ld, bs, j, Linv);
+    hipLaunchKernelGGL(potrf_trinv128_kernel, dim3(batch), dim3(512), POTRF_LDS_DOUBLES * 8, st, A, ld, bs, j, Linv, fail_flag, logdet2);
     const int rem = nt - j - 1;
     if (rem > 0) {
       // panel: L[i,j] = A[i,j] * inv(L_jj)^T, i > j   (rows rem*128, cols 128, k 128); in place
@@ -192,7 +47,6 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
       launch_gemm(st, K_CONTIG, K_CONTIG, rem * NB, rem * NB, batch, q);
     }
   }
-  hipLaunchKernelGGL(logdet_kernel, dim3(batch), dim3(256), 0, st, A, ld, bs, Mp, logdet2);
   // block rows of X = L^-1: X[i,0:i] = -X_ii * (L[i,0:i] * X[0:i,0:i])
   for (int i = 1; i < nt; ++i) {
     GemmP p;
@@ -321,29 +175,44 @@ __global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict
                                                          const double* __restrict__ Bbar, const double* __restrict__ Psi2,
                                                          const double* __restrict__ Z, const double* __restrict__ alpha, int M, int Mp,
                                                          int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart) {
-  __shared__ double red[128];
-  const int j = blockIdx.x;
-  for (int q = 0; q < Q; ++q) {
-    double sz = 0.0, sa = 0.0;
-    const double zj = Z[(long)j * Q + q];
+  // latent dimensions in chunks of 8: the sums of a chunk stay in registers over the row, then one butterfly per sum and one
+  // LDS hand-over between the two waves (the first version ran two 7-step workgroup reductions per latent dimension)
+  constexpr int QC = 8;
+  __shared__ double red[2 * QC];
+  const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q0 = 0; q0 < Q; q0 += QC) {
+    double sz[QC], sa[QC], zj[QC];
+#pragma unroll
+    for (int u = 0; u < QC; ++u) { sz[u] = 0.0; sa[u] = 0.0; zj[u] = (q0 + u < Q) ? Z[(long)j * Q + q0 + u] : 0.0; }
     for (int m = threadIdx.x; m < M; m += 128) {
       const double k = Kmm[(long)j * Mp + m];
-      const double dz = zj - Z[(long)m * Q + q];
-      const double sym = (dFdK[(long)j * Mp + m] + dFdK[(long)m * Mp + j]) * k;
-      sz += sym * dz;
-      double w = -0.5 * dFdK[(long)j * Mp + m] * k;
+      const double fjm = dFdK[(long)j * Mp + m];
+      const double sym = (fjm + dFdK[(long)m * Mp + j]) * k;
+      double w = -0.5 * fjm * k;
       if (!regimeA) w += -0.25 * Bbar[(long)j * Mp + m] * Psi2[(long)j * Mp + m];
-      sa += w * dz * dz;
+#pragma unroll
+      for (int u = 0; u < QC; ++u) {
+        const double dz = zj[u] - ((q0 + u < Q) ? Z[(long)m * Q + q0 + u] : 0.0);
+        sz[u] = fma(sym, dz, sz[u]);
+        sa[u] = fma(w * dz, dz, sa[u]);
+      }
     }
-    red[threadIdx.x] = sz;
+#pragma unroll
+    for (int u = 0; u < QC; ++u)
+      for (int sh = 32; sh > 0; sh >>= 1) { sz[u] += __shfl_xor(sz[u], sh); sa[u] += __shfl_xor(sa[u], sh); }
+    if (wave == 1 && lane == 0) {
+#pragma unroll
+      for (int u = 0; u < QC; ++u) { red[u] = sz[u]; red[QC + u] = sa[u]; }
+    }
     __syncthreads();
-    for (int k = 64; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) gZ[(long)j * Q + q] = -alpha[q] * red[0];
-    __syncthreads();
-    red[threadIdx.x] = sa;
-    __syncthreads();
-    for (int k = 64; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) gapart[(long)j * Q + q] = red[0];
+    if (wave == 0 && lane == 0) {
+#pragma unroll
+      for (int u = 0; u < QC; ++u)
+        if (q0 + u < Q) {
+          gZ[(long)j * Q + q0 + u] = -alpha[q0 + u] * (sz[u] + red[u]);
+          gapart[(long)j * Q + q0 + u] = sa[u] + red[QC + u];
+        }
+    }
     __syncthreads();
   }
 }

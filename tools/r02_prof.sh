@@ -19,7 +19,7 @@ for f in glob.glob('$O/stats/*kernel_stats.csv'):
     rows=list(csv.DictReader(open(f)))
     out += ['%-64s calls=%5s total_ms=%10.3f avg_us=%10.1f pct=%s' % (r['Name'][:64], r['Calls'], float(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e3, r['Percentage']) for r in rows[:40]]
 out.append('')
-KEYS=('p1_kernel','p2_kernel','p2_fast','psi1_kernel')
+KEYS=('p1_kernel','p1v2_kernel','p2_kernel','p2_fast','psi1_kernel','psi2_')
 for tag in ('sq1','sq2','fetch','write'):
     for f in glob.glob('$O/%s/*counter_collection.csv' % tag):
         agg=collections.OrderedDict()
@@ -35,7 +35,7 @@ def avg(tag, counter, key):
     vals=[float(r['Counter_Value']) for f in glob.glob('$O/%s/*counter_collection.csv' % tag) for r in csv.DictReader(open(f)) if key in r['Kernel_Name'] and r['Counter_Name']==counter]
     return sum(vals)/len(vals) if vals else None
 tr={}
-for key,name in (('p2_fast','p2_kernel'),('p1_kernel','p1_kernel'),('psi1_kernel','psi1_kernel')):
+for key,name in (('p2_fast','p2_kernel'),('p1v2_kernel','p1_kernel'),('psi1_kernel','psi1_kernel')):
     f=avg('fetch','FETCH_SIZE',key); w=avg('write','WRITE_SIZE',key)
     if f is not None and w is not None:
         # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) streaming reads -> x2 (MI355X_MICROARCH.md, HBM)

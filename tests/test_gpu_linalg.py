@@ -1,5 +1,5 @@
 """The library's dense FP64 building blocks against numpy (run with -m gpu): the MFMA GEMM core in all four operand layouts -- the
-eight-wave kernel the global step uses for small grids and the four-wave kernel for large ones -- and the blocked Cholesky + inverse."""
+32x32-tile kernel the global step uses for small grids and the 128x128-tile kernel for large ones -- and the blocked Cholesky + inverse."""
 import ctypes
 
 import numpy as np
@@ -22,7 +22,7 @@ def _gemm(ta, tb, m, n, k, alpha, A, B, beta, C):
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('m,n,k', [(100, 70, 50), (512, 512, 512), (300, 129, 1000), (3000, 3000, 40)])
 def test_gemm_layouts(ta, tb, m, n, k):
-    """(3000, 3000): 24 x 24 = 576 tiles -> the four-wave kernel; the others -> the eight-wave kernel (<= 256 workgroups)."""
+    """(3000, 3000): 24 x 24 = 576 tiles of 128 -> the 128x128-tile kernel; the others (<= 256 such tiles) -> the 32x32-tile kernel."""
     rs = np.random.RandomState(m + n + k + 2 * ta + tb)
     A = rs.randn(k, m) if ta else rs.randn(m, k)
     B = rs.randn(n, k) if tb else rs.randn(k, n)

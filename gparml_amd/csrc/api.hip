@@ -202,6 +202,7 @@ static int upload_embeddings(gp_ctx* c, const double* X_mu, const double* X_S, i
   }
   c->xs_raw = xs_is_raw != 0;
   c->regime_A = (!xs_is_raw) && all_zero;
+  c->prep_fixa_valid = false;
   GP_HIP(c, hipMemcpyAsync(c->Xmu, X_mu, nq * 8, hipMemcpyHostToDevice, c->stream));
   GP_HIP(c, hipMemcpyAsync(c->Xs, X_S, nq * 8, hipMemcpyHostToDevice, c->stream));
   GP_HIP(c, hipStreamSynchronize(c->stream));
@@ -239,6 +240,7 @@ extern "C" int gp_upload_shard(gp_ctx* c, const double* Y, const double* X_mu, c
   GP_TRY(upload_embeddings(c, X_mu, X_S, xs_is_raw));
   c->have_data = true;
   c->have_dir = false;
+  c->prep_fixa_valid = false;
   return GP_OK;
 }
 
@@ -611,7 +613,7 @@ extern "C" int gp_cg_update(gp_ctx* c, int which, double a) {
                      c->Xmu, c->Xs);
   GP_HIP(c, hipGetLastError());
   if (which == 0 || which == 1 || which == 5) c->have_dir = true;
-  if (which == 2) c->state = 0;   // the embeddings moved: statistics are stale
+  if (which == 2) { c->state = 0; c->prep_fixa_valid = false; }   // the embeddings moved: statistics are stale
   return GP_OK;
 }
 

@@ -57,6 +57,7 @@ struct gp_ctx {
   bool have_data = false, have_globals = false, have_dir = false, have_glatest = false;
   int state = 0;          // 0 nothing, 1 phase1 done, 2 stats final (global step done), 3 phase2 done
   bool want_emb = false;
+  bool prep_fixa_valid = false;   // regime A, fixed embeddings: the prep kernels' outputs (mu, features, records) are current
 
   // ---- device buffers ----
   double* Kaug = nullptr;     // [Np][LDK]  Psi1 | Y

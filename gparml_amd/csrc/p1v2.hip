@@ -219,9 +219,20 @@ __global__ void __launch_bounds__(256) p1v2_reduce_kernel(const double* __restri
   const int r = e >> 7, c = e & 127;
   if (o.kind == 1 && c < r) return;               // filled by its mirror image
   if (o.kind == 2 && c >= Dp) return;
+  // eight independent partial sums (slices sl, sl + 8, ...) so that eight loads are in flight; the order is fixed
   double s = 0.0;
-  if (o.kind != 2 || c < o.ncols)
-    for (int sl = 0; sl < o.nslices; ++sl) s += part[((long)o.first + (long)sl * o.stride) * (TILE * TILE) + e];
+  if (o.kind != 2 || c < o.ncols) {
+    const double* src = part + (long)o.first * (TILE * TILE) + e;
+    const long step = (long)o.stride * (TILE * TILE);
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int sl = 0;
+    for (; sl + 8 <= o.nslices; sl += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += src[(long)(sl + u) * step];
+    }
+    for (int u = 0; sl < o.nslices; ++sl, ++u) acc[u] += src[(long)sl * step];
+    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
   if (o.kind == 2) {
     C[((long)o.ti * TILE + r) * Dp + c] = s;
   } else {

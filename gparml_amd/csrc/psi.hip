@@ -109,58 +109,81 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 // z_m lives in registers (QP = Q rounded up to 2, zero padded); the packed per-point records PU[n] = [mu_n | u_n | ln c1_n]
 // (written by the prep kernels) are staged through LDS; no guards in the q loop (padding has u = 0).
 constexpr int PSI1_ROWS = 128;   // rows per workgroup of psi1_kernel (Np is a multiple of 128)
-template <int QP>
+// FIXA (fixed embeddings, every variance zero): u_nq = alpha_q and ln c1 = ln sf2 for every point, so the records carry only
+// sqrt(alpha) o mu (scaled while they are staged), z is scaled once per lane and the exponent is -1/2 sum_q (mu' - z')^2:
+// 2 Q + 18 issue slots per element instead of 3 Q + 20, and nothing per point depends on the hyper-parameters (the prep
+// kernels are skipped from the second evaluation on).
+template <int QP, bool FIXA>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
-                                                   long N, long Np, int M, int Mp, int Q, long ld) {
+                                                   long N, long Np, int M, int Mp, int Q, long ld, int WC, const double* __restrict__ alpha,
+                                                   double lnsf2) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
   // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
   // [mu | u | lnc1] records are staged in LDS (below).
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int col = (blockIdx.x * 4 + wave) * 128 + 2 * lane;
+  // WC = waves across the columns (4 for Mp >= 512; 1 or 2 for narrower matrices, where the other 4 / WC waves take every
+  // (4 / WC)-th row of a 16-row group instead of idling: M = 128 ran at a quarter of the rate)
+  const int RG = 4 / WC, rg = wave / WC;
+  const int col = (blockIdx.x * WC + (wave % WC)) * 128 + 2 * lane;
   const long row0 = blockIdx.y * (long)PSI1_ROWS;
   const bool ok0 = col < M, ok1 = col + 1 < M;
   double z0[QP], z1[QP];
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
-    z0[q] = (q < Q && ok0) ? Z[(long)col * Q + q] : 0.0;
-    z1[q] = (q < Q && ok1) ? Z[(long)(col + 1) * Q + q] : 0.0;
+    const double sa = (FIXA && q < Q) ? sqrt(alpha[q]) : 1.0;
+    z0[q] = (q < Q && ok0) ? sa * Z[(long)col * Q + q] : 0.0;
+    z1[q] = (q < Q && ok1) ? sa * Z[(long)(col + 1) * Q + q] : 0.0;
   }
-  constexpr int W = 2 * QP + 2;   // row width of PU (doubles), a multiple of 2
+  constexpr int W = 2 * QP + 2;          // row width of PU (doubles), a multiple of 2
+  constexpr int WS = FIXA ? QP : W;      // staged doubles per row
   // Records of 16 rows at a time: one coalesced load into LDS, read back as broadcast operands; the next group's records
   // travel while the current group is computed.  (Per-row scalar loads cost a serial memory round trip per row and held the
   // kernel at 1.9 ms although plain stores reach 5.5 TB/s: tools/ubench/store_ubench.hip.)
-  constexpr int GR = 16, NG = PSI1_ROWS / GR, RPT = (GR * W + 255) / 256;
-  __shared__ double rec_s[2][GR * W];
+  constexpr int GR = 16, NG = PSI1_ROWS / GR, RPT = (GR * WS + 255) / 256;
+  __shared__ double rec_s[2][GR * WS];
   double stage[RPT];
+  auto fetch = [&](int g, int i) -> double {
+    const int e = threadIdx.x + 256 * i;
+    if (e >= GR * WS) return 0.0;
+    if (!FIXA) return PU[(row0 + GR * g) * W + e];
+    const int r = e / QP, q = e - r * QP;
+    return (q < Q ? sqrt(alpha[q]) : 0.0) * PU[(row0 + GR * g + r) * W + q];
+  };
 #pragma unroll
-  for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * W) rec_s[0][e] = PU[row0 * W + e]; }
+  for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * WS) rec_s[0][e] = fetch(0, i); }
   __syncthreads();
   for (int g = 0; g < NG; ++g) {
     if (g + 1 < NG) {
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; stage[i] = e < GR * W ? PU[(row0 + GR * (g + 1)) * W + e] : 0.0; }
+      for (int i = 0; i < RPT; ++i) stage[i] = fetch(g + 1, i);
     }
     const double* recs = rec_s[g & 1];
 #pragma unroll 1
-    for (int r = 0; r < GR; ++r) {
+    for (int r = rg; r < GR; r += RG) {
       const long n = row0 + GR * g + r;       // Np is a multiple of 128: always in range
-      const double* row = recs + r * W;
+      const double* row = recs + r * WS;
       double e0 = 0.0, e1 = 0.0;
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
         const double d0 = row[q] - z0[q], d1 = row[q] - z1[q];
-        e0 = fma(row[QP + q] * d0, d0, e0);
-        e1 = fma(row[QP + q] * d1, d1, e1);
+        if (FIXA) {
+          e0 = fma(d0, d0, e0);
+          e1 = fma(d1, d1, e1);
+        } else {
+          e0 = fma(row[QP + q] * d0, d0, e0);
+          e1 = fma(row[QP + q] * d1, d1, e1);
+        }
       }
+      const double l0 = FIXA ? lnsf2 : row[2 * QP];
       double2 v;
-      v.x = (n < N && ok0) ? fexp(row[2 * QP] - 0.5 * e0) : 0.0;
-      v.y = (n < N && ok1) ? fexp(row[2 * QP] - 0.5 * e1) : 0.0;
+      v.x = (n < N && ok0) ? fexp(fma(-0.5, e0, l0)) : 0.0;
+      v.y = (n < N && ok1) ? fexp(fma(-0.5, e1, l0)) : 0.0;
       if (col < Mp) *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
     }
     if (g + 1 < NG) {
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * W) rec_s[(g + 1) & 1][e] = stage[i]; }
+      for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * WS) rec_s[(g + 1) & 1][e] = stage[i]; }
     }
     __syncthreads();
   }
@@ -315,9 +338,15 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 }
 
 template <int QP>
-static void launch_psi1(gp_ctx* c) {
-  dim3 grid((c->Mp + 511) / 512, (unsigned)(c->Np / PSI1_ROWS));
-  hipLaunchKernelGGL((psi1_kernel<QP>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q, (long)c->LDK);
+static void launch_psi1(gp_ctx* c, bool fixa) {
+  const int WC = c->Mp >= 512 ? 4 : (c->Mp >= 256 ? 2 : 1);
+  dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)(c->Np / PSI1_ROWS));
+  if (fixa)
+    hipLaunchKernelGGL((psi1_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                       (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2));
+  else
+    hipLaunchKernelGGL((psi1_kernel<QP, false>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                       (long)c->LDK, WC, (const double*)c->alpha, 0.0);
 }
 
 int run_prep_and_generate(gp_ctx* c) {
@@ -327,21 +356,28 @@ int run_prep_and_generate(gp_ctx* c) {
   a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CXp = c->CXp; a.step = c->step; a.sf2 = c->sf2;
   a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = p2_fast_mode(c) ? 1 : 0;
   a.QP = (c->Q + 1) / 2 * 2; a.PU = a.QP <= 16 ? c->PU : nullptr;
-  hipLaunchKernelGGL(prep_elem_kernel, dim3((unsigned)std::min<long>((c->Np * c->Q + 255) / 256, 16384)), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(prep_row_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
-  GP_HIP(c, hipGetLastError());
+  // Fixed embeddings with every variance zero (regime A, no embedding gradients): the trial point is X_mu itself, S = 0, the
+  // feature matrix is [mu | 1] and KL = 0 -- nothing the prep kernels write depends on the hyper-parameters, so they run once per
+  // upload / mode switch; Psi1 then takes alpha and sf2 as arguments (psi1_kernel<QP, true>).
+  const bool fixa = a.fixedA && a.PU != nullptr;
+  if (!(fixa && c->prep_fixa_valid)) {
+    hipLaunchKernelGGL(prep_elem_kernel, dim3((unsigned)std::min<long>((c->Np * c->Q + 255) / 256, 16384)), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(prep_row_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, a);
+    GP_HIP(c, hipGetLastError());
+  }
+  c->prep_fixa_valid = fixa;
   (void)hipEventRecord(c->ev[8], c->stream);
   const int QP = (c->Q + 1) / 2 * 2;
   if (QP <= 16) {
     switch (QP) {
-      case 2: launch_psi1<2>(c); break;
-      case 4: launch_psi1<4>(c); break;
-      case 6: launch_psi1<6>(c); break;
-      case 8: launch_psi1<8>(c); break;
-      case 10: launch_psi1<10>(c); break;
-      case 12: launch_psi1<12>(c); break;
-      case 14: launch_psi1<14>(c); break;
-      default: launch_psi1<16>(c); break;
+      case 2: launch_psi1<2>(c, fixa); break;
+      case 4: launch_psi1<4>(c, fixa); break;
+      case 6: launch_psi1<6>(c, fixa); break;
+      case 8: launch_psi1<8>(c, fixa); break;
+      case 10: launch_psi1<10>(c, fixa); break;
+      case 12: launch_psi1<12>(c, fixa); break;
+      case 14: launch_psi1<14>(c, fixa); break;
+      default: launch_psi1<16>(c, fixa); break;
     }
   } else {
     dim3 grid(c->Mp / 128, (unsigned)(c->Np / 64));

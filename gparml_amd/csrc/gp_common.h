@@ -132,6 +132,10 @@ struct gp_ctx {
   double* alphaP = nullptr;   // [QB]      alpha, zero-padded
   double* Z1P = nullptr;      // [Mp][QB]  Z with a column of ones at index Q (only meaningful when QB > Q)
   bool b_mfma = false;        // regime-B phase 2 on the matrix core (Q >= 17)
+  bool b_sym = false;         // regime-B phase 2 on tile pairs (psi2_sym_kernel: Q <= 10, 64 < M <= 1024)
+  double* Z1S = nullptr;      // [Mp][RT]  [Z | 1 at index QB | 0], RT = QB + 1 rounded up to 4: B operand of the row-side MFMAs
+  int* sym_sched = nullptr;   // [rounds][waves] tile of every wave in every round (I | J << 16, -1 idle)
+  int sym_nw = 0, sym_rounds = 0;
   double* ZP = nullptr;       // [Mp][QB]  Z zero-padded (rows >= M and columns >= Q are zero)
   int QB = 0;                 // 4, 10, 16, 32 or 64: smallest instantiated width >= Q
   double* lnc2h = nullptr;    // [Np]      1/2 ln c2_n

@@ -9,6 +9,7 @@
 #include "gp_common.h"
 #include "mma_f64.h"
 #include "fexp.h"
+#include "quad_mma.h"
 #include <algorithm>
 
 namespace gp {
@@ -101,13 +102,22 @@ __global__ void __launch_bounds__(256) dz2_kernel(const double* __restrict__ Z, 
 }
 
 __global__ void __launch_bounds__(256) zpad_kernel(const double* __restrict__ Z, int M, int Mp, int Q, int QB, double* __restrict__ ZP,
-                                                    double* __restrict__ Z1P) {
+                                                    double* __restrict__ Z1P, double* __restrict__ Z1S, int RT) {
   const long total = (long)Mp * QB;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const int q = (int)(i % QB), m = (int)(i / QB);
     const double z = (m < M && q < Q) ? Z[(long)m * Q + q] : 0.0;
     ZP[i] = z;
     Z1P[i] = (q == Q) ? 1.0 : z;          // Z with a column of ones at index Q (the MFMA kernel's row-sum column)
+  }
+  if (Z1S) {
+    // [Z | 1 at index QB | 0]: the tile-pair kernel's row-side operand (padded rows are all zero except the ones column, which
+    // only ever multiplies T = 0 there)
+    const long tot2 = (long)Mp * RT;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < tot2; i += (long)gridDim.x * 256L) {
+      const int f = (int)(i % RT), m = (int)(i / RT);
+      Z1S[i] = (f < Q && m < M) ? Z[(long)m * Q + f] : (f == QB ? 1.0 : 0.0);
+    }
   }
 }
 
@@ -315,6 +325,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+
 template <int QT, bool KEEP>
 __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_cols_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
                                                         const double* __restrict__ LEA, const double* __restrict__ V2P,
@@ -391,6 +402,136 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_c
   if (KEEP && active && mc < a.M) {
 #pragma unroll
     for (int q = 0; q < QT; ++q) if (q < a.Q) G[(long)mc * a.Q + q] = g[q];
+  }
+}
+
+// ---- the same on tile PAIRS (Q <= 10, M <= 1024): T_n is symmetric, so a 64 x 64 tile (I < J) of it serves the column sums of
+// slab J AND the row sums of slab I; only the exponent, the exp and the product with Bbar -- half of the work of the column
+// kernel above -- are shared, the Q + 1 accumulations per pair are needed on both sides.
+//   column side: as above, lane = column of slab J, rows of slab I as scalar operands (2 Q + 20 issue slots per pair);
+//   row side:    r_m, t_m[q] = sum over the lanes -- a reduction across the wave, done on the matrix core: the T values of four
+//                rows are transposed inside each lane quad (quad_perm moves), which makes them the A operand of
+//                v_mfma_f64_4x4x4_4b (A_b[i][k] = T[m0 + i][16 k + 4 b + v]); B_b[k][j] = [Z | 1][16 k + 4 b + v][4 qq + j] comes
+//                from registers; four blocks b x four v cover the 64 columns, the block partials are added with two row
+//                rotations.  4 (Q + 2) / 4 MFMAs per 4 rows x 64 columns = the VALU cost of the accumulation, no LDS traffic.
+// Both sides add into one LDS array rt[M][Q + 2] per point.  The tiles of a point are scheduled as a round-robin tournament over
+// the slabs (a round = disjoint slab pairs, one per wave, rounds separated by a barrier), so no two waves ever touch the same rows
+// of rt at the same time: plain read-add-write in a fixed order, no atomics, results bit-identical from run to run.  When all
+// rounds are done every thread finishes its rows (grad_Z of the row, the per-point sums) exactly as the column kernel does.
+template <int QT>
+__global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
+                                                       const double* __restrict__ Bbar, const double* __restrict__ LEA,
+                                                       const double* __restrict__ V2P, const double* __restrict__ WP,
+                                                       const double* __restrict__ MUP, const double* __restrict__ alphaP,
+                                                       const int* __restrict__ sched, int nrounds) {
+  constexpr int RT = (QT + 1 + 3) / 4 * 4, NQ = RT / 4, PW = 3 * QT + 1;
+  extern __shared__ double smem[];
+  double* rt = smem;                       // [Mp][RT]   t_m[q] (q < QT), r_m (index QT) of the current point
+  double* red = rt + (long)a.Mp * RT;      // [waves][PW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;
+  const long n0 = (long)blockIdx.x * a.ppb, n1 = min(a.N, n0 + a.ppb);
+  for (int i = tid; i < a.Mp * RT; i += blockDim.x) rt[i] = 0.0;
+  __syncthreads();
+  const int lq = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
+  for (long n = n0; n < n1; ++n) {
+    const double* v2 = V2P + n * QT;                   // wave-uniform
+    const double* lrow = LEA + n * a.Mp;
+    for (int rd = 0; rd < nrounds; ++rd) {
+      const int code = sched[rd * nw + wave];          // wave-uniform: I | J << 16, -1 = idle
+      if (code >= 0) {
+        const int I = code & 0xffff, J = code >> 16;
+        const bool offd = I != J;
+        const int mc = 64 * J + lane;
+        double zz[QT], t[QT], r = 0.0;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * ZP[(long)mc * QT + q]; t[q] = 0.0; }
+        const double lea = lrow[mc];
+        const double* bcol = Bbar + mc;
+        double ZB[4][NQ];
+        if (offd) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = Z1S[(long)(64 * J + 16 * lk + 4 * lb + v) * RT + 4 * qq + lq];
+        }
+        double bbn[4];                                      // Bbar of the next group of rows, one group ahead
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(64 * I + u) * a.Mp];
+        for (int g = 0; g < 16; ++g) {
+          const int m0 = 64 * I + 4 * g;
+          double bb[4], T[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bb[u] = bbn[u];
+          if (g + 1 < 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(m0 + 4 + u) * a.Mp];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double* zm = ZP + (long)(m0 + u) * QT;    // wave-uniform: scalar loads (an explicit one-row-ahead request of
+            double e = lrow[m0 + u] + lea;                  // these operands made hipcc spill SGPRs through v_writelane: +20 %)
+#pragma unroll
+            for (int q = 0; q < QT; ++q) e = fma(zm[q], zz[q], e);
+            T[u] = bb[u] * fexp(e);
+            r += T[u];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) t[q] = fma(T[u], zm[q], t[q]);
+          }
+          if (offd) {
+            double acc[NQ];
+            wave_rows_times_features<NQ>(T, ZB, acc);
+            if (lb == 0) {
+              double* dst = rt + (m0 + lk) * RT + lq;
+#pragma unroll
+              for (int qq = 0; qq < NQ; ++qq) dst[4 * qq] += acc[qq];
+            }
+          }
+        }
+        // column side of this tile into rt (rows of slab J)
+        double* dst = rt + mc * RT;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) dst[q] += t[q];
+        dst[QT] += r;
+      }
+      __syncthreads();
+    }
+    // ---- finish the point: every thread takes rows tid, tid + blockDim.x, ... (and clears them for the next point)
+    const double* wn = WP + n * QT;                      // wave-uniform
+    const double* mun = MUP + n * QT;
+    double s0 = 0.0, s1[QT], s2[QT], s3[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) { s1[q] = 0.0; s2[q] = 0.0; s3[q] = 0.0; }
+    for (int m = tid; m < a.Mp; m += blockDim.x) {
+      double* src = rt + m * RT;
+      const double r = src[QT];
+      src[QT] = 0.0;
+      s0 += r;
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        const double tq = src[q];
+        src[q] = 0.0;
+        const double zq = ZP[(long)m * QT + q];
+        const double gq = -alphaP[q] * (zq * r - tq) + wn[q] * (2.0 * mun[q] * r - zq * r - tq);
+        if (m < a.M && q < a.Q) { double* d = G + (long)m * a.Q + q; *d = ((n == n0) ? 0.0 : *d) + gq; }
+        s1[q] = fma(zq, r, s1[q]); s2[q] = fma(zq * zq, r, s2[q]); s3[q] = fma(zq, tq, s3[q]);
+      }
+    }
+    s0 = wave_sum(s0);
+    if (lane == 0) red[wave * PW] = s0;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const double x1 = wave_sum(s1[q]), x2 = wave_sum(s2[q]), x3 = wave_sum(s3[q]);
+      if (lane == 0) { red[wave * PW + 1 + q] = x1; red[wave * PW + 1 + QT + q] = x2; red[wave * PW + 1 + 2 * QT + q] = x3; }
+    }
+    __syncthreads();
+    for (int i = tid; i < PW; i += blockDim.x) {
+      double sum = red[i];
+      for (int w = 1; w < nw; ++w) sum += red[w * PW + i];
+      a.pp[(long)i * a.Np + n] = sum;
+    }
+    // red is rewritten only behind the next point's round barriers; rt rows were cleared before the barrier above
   }
 }
 
@@ -666,7 +807,33 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   for (int i = 0; i < Mt64; ++i) for (int j = i; j < Mt64; ++j) { t64.push_back(i); t64.push_back(j); }
   c->n_tiles64 = (int)t64.size() / 2;
   A(&c->tiles64, t64.size());
+  // tile-pair phase 2 (psi2_sym_kernel): Q <= 10, three to sixteen 64-column slabs (two slabs = a single wave per workgroup
+  // running three tiles one after the other: slower than the column kernel, configs[1] 4.9 -> 5.2 ms).  Schedule = round-robin tournament over the
+  // slabs (circle method; an odd count gets a bye) followed by the diagonal tiles, one tile per wave and round.
+  // ... and its per-point array rt (Mp x RT doubles of LDS per workgroup) must leave room for twelve waves per CU: with fewer
+  // the scalar-operand latency is exposed and the column kernel (four waves per SIMD) is faster (M = 1024: one workgroup per CU)
+  {
+    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2, RTs = (c->QB + 1 + 3) / 4 * 4;
+    const size_t smem = ((size_t)Mp * RTs + (size_t)nw * (3 * c->QB + 1)) * sizeof(double);
+    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
+  }
+  std::vector<int> sch;
+  if (c->b_sym) {
+    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2;
+    for (int r = 0; r < nv - 1; ++r)
+      for (int k = 0; k < nw; ++k) {
+        const int x = (k == 0) ? nv - 1 : (r + k) % (nv - 1), y = (k == 0) ? r : (r - k + (nv - 1)) % (nv - 1);
+        const int I = std::min(x, y), J = std::max(x, y);
+        sch.push_back(J < c->nslab ? (I | (J << 16)) : -1);
+      }
+    for (int d = 0; d < c->nslab; d += nw)
+      for (int k = 0; k < nw; ++k) sch.push_back(d + k < c->nslab ? ((d + k) | ((d + k) << 16)) : -1);
+    c->sym_nw = nw; c->sym_rounds = (int)sch.size() / nw;
+    A(&c->Z1S, (size_t)Mp * ((c->QB + 1 + 3) / 4 * 4));
+    A(&c->sym_sched, sch.size());
+  }
   if (rc != GP_OK) return rc;
+  if (c->b_sym) GP_HIP(c, hipMemcpyAsync(c->sym_sched, sch.data(), sch.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   GP_HIP(c, hipMemcpyAsync(c->ptiles, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   GP_HIP(c, hipMemcpyAsync(c->tiles64, t64.data(), t64.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   GP_HIP(c, hipStreamSynchronize(c->stream));
@@ -704,8 +871,8 @@ int run_generate_b(gp_ctx* c) {
   hipLaunchKernelGGL(b_tables_kernel, dim3(c->kl_blocks), dim3(256), 0, c->stream, c->mu, c->S, c->alpha, (long)c->N, (long)c->Np, c->Q,
                      c->sf2, c->Vn, c->Wn, c->lnc2h, c->V2P, c->QB, c->WP, c->MUP);
   GP_HIP(c, hipMemcpyAsync(c->alphaP, c->alpha, (size_t)c->Q * 8, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(zpad_kernel, dim3((unsigned)(((long)c->Mp * c->QB + 255) / 256)), dim3(256), 0, c->stream, c->Z, c->M, c->Mp, c->Q, c->QB,
-                     c->ZP, c->Z1P);
+  hipLaunchKernelGGL(zpad_kernel, dim3((unsigned)(((long)c->Mp * (c->QB + 6) + 255) / 256)), dim3(256), 0, c->stream, c->Z, c->M, c->Mp, c->Q, c->QB,
+                     c->ZP, c->Z1P, c->b_sym ? c->Z1S : nullptr, (c->QB + 1 + 3) / 4 * 4);
   switch (c->QB) {
     case 4: launch_le<4, 2>(c); break;
     case 10: launch_le<10, 2>(c); break;
@@ -774,6 +941,17 @@ static void launch_cols(gp_ctx* c, const PB2Args& a) {
 }
 
 template <int QT>
+static int launch_sym(gp_ctx* c, const PB2Args& a) {
+  constexpr int RT = (QT + 1 + 3) / 4 * 4;
+  const size_t smem = ((size_t)c->Mp * RT + (size_t)c->sym_nw * (3 * QT + 1)) * sizeof(double);
+  GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_sym_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL((psi2_sym_kernel<QT>), dim3(c->pb_blocks), dim3(64 * c->sym_nw), smem, c->stream, a, (const double*)c->ZP, (const double*)c->Z1S,
+                     (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
+                     (const double*)c->alphaP, (const int*)c->sym_sched, c->sym_rounds);
+  return GP_OK;
+}
+
+template <int QT>
 static int launch_cols_mfma(gp_ctx* c, const PB2Args& a) {
   constexpr int LDZ = QT + 2;
   const size_t smem = ((size_t)(2 * 32 + 4 * 16) * LDZ + c->Mp + 4 * (3 * QT + 1)) * sizeof(double);
@@ -800,6 +978,10 @@ int run_phase2_b(gp_ctx* c) {
       case 52: rc = launch_cols_mfma<52>(c, a); break;
       default: rc = launch_cols_mfma<64>(c, a); break;
     }
+    if (rc != GP_OK) return rc;
+  } else if (c->b_sym) {
+    a.ngrp = 1;
+    int rc = c->QB == 4 ? launch_sym<4>(c, a) : launch_sym<10>(c, a);
     if (rc != GP_OK) return rc;
   } else
   switch (c->QB) {

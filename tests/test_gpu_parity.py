@@ -78,6 +78,8 @@ SHAPES = [
     # every compiled latent width (4/10/16/24/32/52/64) and more than four 64-column slabs of inducing points
     (500, 3, 300, 5, 'B', 1.0), (400, 2, 70, 20, 'B', 0.1), (300, 2, 40, 30, 'B', 0.08), (200, 2, 24, 50, 'B', 0.05),
     (150, 2, 12, 60, 'B', 0.05),
+    # the tile-pair phase 2 (psi2_sym_kernel): eight slabs (four waves, nine rounds), an odd slab count with a bye, both latent widths
+    (600, 3, 512, 10, 'B', 0.3), (260, 2, 200, 4, 'B', 4.0), (800, 2, 700, 7, 'B', 0.3),
 ]
 
 

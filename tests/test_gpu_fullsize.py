@@ -86,3 +86,31 @@ def test_map_reduce_identity_and_directional_derivative(N, D, M, Q, regime):
     eng.close()
     fd = (Fs[0] - Fs[1]) / (2 * scale)
     assert abs(fd - ana) <= 2e-5 * abs(ana) + 1e-6 * abs(ref['F']) * 1e-3, 'directional derivative: fd %.10e vs analytic %.10e' % (fd, ana)
+
+
+def test_full_size_against_the_blas_port():
+    """BASELINE configs[2] at its FULL size (N=1e6, D=100, M=512, Q=10, fixed embeddings -- the kernel sequence bench.py times)
+    against the CPU port arranged for BLAS (oracle/factorised.evaluate_blas, ~13 s on the GPU box's host; checked against the
+    kernel-spec port by tests/test_oracle_factorised.py).  Two hyper-parameter sets on the same data:
+      alpha = 0.3: well conditioned -- measured F 3e-14, grad_Z 7e-10, the other gradients <= 1e-12 (relative to the block's
+                   largest magnitude); asserted at 1e-9 / 1e-7;
+      alpha = 0.1: the benchmark's value -- cond(K_mm + beta Psi2) grows with N and grad_Z is a 70-fold cancellation (DESIGN.md
+                   section 6: two float64 CPU paths already differ by 8e-5 at N = 2e5), measured F 1e-11, grad_Z 2.8e-5,
+                   grad_alpha 6e-9, grad_sf2 4e-10, grad_beta 5e-13; asserted at 1e-8 for F, 2e-4 for grad_Z, 1e-6 for the rest."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import factorised as Fz
+    N, D, M, Q = 1000000, 100, 512, 10
+    d = _synthetic(N, D, M, Q, 'A')
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    work = {}
+    for alpha, f_tol, gz_tol, g_tol in ((0.3, 1e-9, 1e-7, 1e-7), (0.1, 1e-8, 2e-4, 1e-6)):
+        al = np.full(Q, alpha)
+        ref = Fz.evaluate_blas(d['Z'], d['sf2'], al, d['beta'], d['Y'], d['X_mu'], work=work)
+        eng.set_globals(d['Z'], d['sf2'], al, d['beta'])
+        out = eng.evaluate(False)
+        assert_close(out['F'], ref['F'], f_tol, what='F (alpha %.1f)' % alpha)
+        assert_close(out['grad_Z'], ref['grad_Z'], gz_tol, what='grad_Z (alpha %.1f)' % alpha)
+        for k in ('grad_alpha', 'grad_sf2', 'grad_beta'):
+            assert_close(out[k], ref[k], g_tol, what='%s (alpha %.1f)' % (k, alpha))
+    eng.close()

@@ -14,6 +14,11 @@
 
 namespace gp {
 
+template <int I> struct B2IC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void b2for(F&& f) {
+  if constexpr (B < E) { f(B2IC<B>{}); b2for<B + 1, E>(f); }
+}
 
 // ---------------------------------------------------------------------------------------------- tables
 // per-point tables and LE in both layouts; thread = point for LET (coalesced along n), thread = column for LE
@@ -246,26 +251,30 @@ __global__ void __launch_bounds__(256, 2) psi2_pairs_mfma_kernel(const double* _
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int cq = 0; cq < 4; ++cq) E[rb][cq] = 0.0;
-    double av[2][4], bv[2][4];
+    {
+      // explicit ds_read_b64 operand reads with counted waits, asm MFMAs (see psi2_cols_mfma_kernel: hipcc's ds_read2_b64 merge
+      // makes the A reads 2-way bank conflicts)
+      const unsigned aA = lds_byte_addr(zr) + 8u * (unsigned)aofs, aB = lds_byte_addr(zzw) + 8u * (unsigned)bofs;
+      double av[2][4], bv[2][4];
+      auto rd = [&](auto kc, double (&a_)[4], double (&b_)[4]) {
+        constexpr int k4 = decltype(kc)::value;
+        b2for<0, 4>([&](auto rc) { constexpr int rb = decltype(rc)::value; a_[rb] = ds_read64<(16 * rb * LDZ + 4 * k4) * 8>(aA); });
+        b2for<0, 4>([&](auto cc) { constexpr int cq = decltype(cc)::value; b_[cq] = ds_read64<(4 * cq * LDZ + 4 * k4) * 8>(aB); });
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own ZZ_n stores above have landed
+      rd(B2IC<0>{}, av[0], bv[0]);
+      b2for<0, NQ>([&](auto kc) {
+        constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
+        if constexpr (k4 + 1 < NQ) { rd(B2IC<k4 + 1>{}, av[cur ^ 1], bv[cur ^ 1]); lgkm_wait<8>(); }
+        else lgkm_wait<0>();
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) av[0][rb] = zr[aofs + 16 * rb * LDZ];
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-    for (int cq = 0; cq < 4; ++cq) bv[0][cq] = zzw[bofs + 4 * cq * LDZ];
+          for (int cq = 0; cq < 4; ++cq) mfma444_acc(E[rb][cq], av[cur][rb], bv[cur][cq]);
+      });
+      mfma_drain(E[3][3]);
 #pragma unroll
-    for (int k4 = 0; k4 < NQ; ++k4) {
-      const int cur = k4 & 1, nxt = cur ^ 1;
-      if (k4 + 1 < NQ) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) av[nxt][rb] = zr[aofs + 16 * rb * LDZ + 4 * (k4 + 1)];
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) bv[nxt][cq] = zzw[bofs + 4 * cq * LDZ + 4 * (k4 + 1)];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) E[rb][cq] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cur][rb], bv[cur][cq], E[rb][cq], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int rb = 0; rb < 4; ++rb) acc_fence<4>(E[rb]);
     }
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -608,57 +617,66 @@ __global__ void __launch_bounds__(256, 2) psi2_cols_mfma_kernel(PB2Args a, const
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) bb[rb][cq] = brow[4 * cq];
       }
-      // GEMM1 (operands of step k4+1 are read while the 16 MFMAs of step k4 execute)
+      // GEMM1 (operands of step k4+1 are read while the 8 MFMAs of step k4 execute).  Operand reads are explicit ds_read_b64 with
+      // counted waits and the MFMAs asm (mma_f64.h): left to hipcc, the two A reads of a step merge into ds_read2_b64, which is
+      // serviced in 16-lane groups over 32 banks and turns the stride-(QT+2) image into a 2-way conflict (PMC: 3.4e9 conflict
+      // cycles against 5.1e9 active LDS cycles per launch at Q = 50, M = 1024)
       double E[RB][4];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) E[rb][cq] = 0.0;
-      double av[2][RB], bv[2][4];
+      {
+        const unsigned aA = lds_byte_addr(zb) + 8u * (unsigned)aofs, aB = lds_byte_addr(zzw) + 8u * (unsigned)bofs;
+        double av[2][RB], bv[2][4];
+        auto rd = [&](auto kc, double (&a_)[RB], double (&b_)[4]) {
+          constexpr int k4 = decltype(kc)::value;
+          b2for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; a_[rb] = ds_read64<(16 * rb * LDZ + 4 * k4) * 8>(aA); });
+          b2for<0, 4>([&](auto cc) { constexpr int cq = decltype(cc)::value; b_[cq] = ds_read64<(4 * cq * LDZ + 4 * k4) * 8>(aB); });
+        };
+        rd(B2IC<0>{}, av[0], bv[0]);
+        b2for<0, NQ>([&](auto kc) {
+          constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
+          if constexpr (k4 + 1 < NQ) { rd(B2IC<k4 + 1>{}, av[cur ^ 1], bv[cur ^ 1]); lgkm_wait<RB + 4>(); }
+          else lgkm_wait<0>();
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) av[0][rb] = zb[aofs + 16 * rb * LDZ];
+          for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int cq = 0; cq < 4; ++cq) bv[0][cq] = zzw[bofs + 4 * cq * LDZ];
+            for (int cq = 0; cq < 4; ++cq) mfma444_acc(E[rb][cq], av[cur][rb], bv[cur][cq]);
+        });
+        mfma_drain(E[RB - 1][3]);
 #pragma unroll
-      for (int k4 = 0; k4 < NQ; ++k4) {
-        const int cur = k4 & 1, nxt = cur ^ 1;
-        if (k4 + 1 < NQ) {
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) av[nxt][rb] = zb[aofs + 16 * rb * LDZ + 4 * (k4 + 1)];
-#pragma unroll
-          for (int cq = 0; cq < 4; ++cq) bv[nxt][cq] = zzw[bofs + 4 * cq * LDZ + 4 * (k4 + 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-          for (int cq = 0; cq < 4; ++cq) E[rb][cq] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cur][rb], bv[cur][cq], E[rb][cq], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int rb = 0; rb < RB; ++rb) acc_fence<4>(E[rb]);
       }
       // T = Bbar o exp(E + LEA[n, row] + LEA[n, col]) on the result registers
-      double b2[2][RB];
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) b2[0][rb] = zb[b2ofs + 16 * rb * LDZ];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const double lr = lrow[r0 + 16 * rb + 4 * lb + lk];
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) E[rb][cq] = bb[rb][cq] * fexp(E[rb][cq] + lr + lcol[cq]);
       }
-      // GEMM2: tacc[cq][qq] += sum_rb T[rb][cq]^T . B2[rb][qq]
+      // GEMM2: tacc[cq][qq] += sum_rb T[rb][cq]^T . B2[rb][qq]   (same read / wait scheme; the s_nop covers the VALU -> MFMA
+      // operand hazard the compiler cannot see through the asm)
+      {
+        const unsigned aB2 = lds_byte_addr(zb) + 8u * (unsigned)b2ofs;
+        double b2[2][RB];
+        auto rd2 = [&](auto qc, double (&b_)[RB]) {
+          constexpr int qq = decltype(qc)::value;
+          b2for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; b_[rb] = ds_read64<(16 * rb * LDZ + 4 * qq) * 8>(aB2); });
+        };
+        rd2(B2IC<0>{}, b2[0]);
 #pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) {
-        const int cur = qq & 1, nxt = cur ^ 1;
-        if (qq + 1 < NQ) {
+        for (int rb = 0; rb < RB; ++rb) acc_fence<4>(E[rb]);
+        asm volatile("s_nop 4");
+        b2for<0, NQ>([&](auto qc) {
+          constexpr int qq = decltype(qc)::value, cur = qq & 1;
+          if constexpr (qq + 1 < NQ) { rd2(B2IC<qq + 1>{}, b2[cur ^ 1]); lgkm_wait<RB>(); }
+          else lgkm_wait<0>();
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) b2[nxt][rb] = zb[b2ofs + 16 * rb * LDZ + 4 * (qq + 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+          for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-          for (int cq = 0; cq < 4; ++cq) tacc[cq][qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(E[rb][cq], b2[cur][rb], tacc[cq][qq], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int cq = 0; cq < 4; ++cq) mfma444_acc(tacc[cq][qq], E[rb][cq], b2[cur][rb]);
+        });
       }
       if (s + 1 < nstrip) {
         double* zn = zs + ((s + 1) & 1) * SR * LDZ;
@@ -670,6 +688,9 @@ __global__ void __launch_bounds__(256, 2) psi2_cols_mfma_kernel(PB2Args a, const
     // ---- per point: add the four row-quad partials (lanes that differ in bits 2,3), then lane (lk, li) holds
     //      t[column c0 + 4 cq + lk][q = 4 qq + li] in every block
     const int Qq = a.Q >> 2, Qj = a.Q & 3;          // the ones column (index Q) sits in quad Qq, position Qj
+    mfma_drain(tacc[3][NQ - 1]);
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) acc_fence<NQ>(tacc[cq]);
     double rcol[4];
 #pragma unroll
     for (int cq = 0; cq < 4; ++cq) {

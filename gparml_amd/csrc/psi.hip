@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   const int col = (blockIdx.x * WC + (wave % WC)) * 128 + 2 * lane;
   const long row0 = blockIdx.y * (long)PSI1_ROWS;
   const bool ok0 = col < M, ok1 = col + 1 < M;
+  const ExpTab xt = exp_tab_lane();
   double z0[QP], z1[QP];
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
@@ -176,9 +177,10 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
         }
       }
       const double l0 = FIXA ? lnsf2 : row[2 * QP];
+      const double x0 = fexp_t(fma(-0.5, e0, l0), xt), x1 = fexp_t(fma(-0.5, e1, l0), xt);   // all lanes (cross-lane table lookup), then select
       double2 v;
-      v.x = (n < N && ok0) ? fexp(fma(-0.5, e0, l0)) : 0.0;
-      v.y = (n < N && ok1) ? fexp(fma(-0.5, e1, l0)) : 0.0;
+      v.x = (n < N && ok0) ? x0 : 0.0;
+      v.y = (n < N && ok1) ? x1 : 0.0;
       if (col < Mp) *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
     }
     if (g + 1 < NG) {

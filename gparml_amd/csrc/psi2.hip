@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
   const long n0 = slice * per, n1 = min(N, n0 + per);
   const double* l1 = LE + m1;
   const double* l2 = LE + m2;
+  const ExpTab xt = exp_tab_lane();
   double acc0 = 0.0, acc1 = 0.0;
   long n = n0;
   for (; n + 4 <= n1; n += 4) {
@@ -162,15 +163,15 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
 #pragma unroll
       for (int q = 0; q < QT; ++q) e[u] = fma(v[q], dz[q], e[u]);
     }
-    acc0 += fexp(e[0]) + fexp(e[2]);
-    acc1 += fexp(e[1]) + fexp(e[3]);
+    acc0 += fexp_t(e[0], xt) + fexp_t(e[2], xt);
+    acc1 += fexp_t(e[1], xt) + fexp_t(e[3], xt);
   }
   for (; n < n1; ++n) {
     double e = l1[n * Mp] + l2[n * Mp];
     const double* v = V2P + n * QT;
 #pragma unroll
     for (int q = 0; q < QT; ++q) e = fma(v[q], dz[q], e);
-    acc0 += fexp(e);
+    acc0 += fexp_t(e, xt);
   }
   part[((long)slice * T + tile) * 256 + threadIdx.x] = acc0 + acc1;
 }

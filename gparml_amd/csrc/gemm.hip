@@ -83,11 +83,6 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
 //   LDS image of an operand chunk: K_CONTIG  [32 free][128 k], row stride 130  (16 rows x {k, k+1} cover 32 distinct 8-byte slots)
 //                                  FREE_CONTIG [128 k][32 free], row stride 48 (k and k+1 sit 16 slots apart)
 // Operand reads are explicit ds_read_b64 with counted lgkmcnt waits (mma_f64.h).
-template <int I> struct GIC { static constexpr int value = I; };
-template <int B, int E, typename F>
-__device__ __forceinline__ void gfor(F&& f) {
-  if constexpr (B < E) { f(GIC<B>{}); gfor<B + 1, E>(f); }
-}
 
 constexpr int ST = 32;     // workgroup tile of the small kernel
 constexpr int SKC = 128;   // its k-chunk
@@ -157,15 +152,15 @@ __global__ void __launch_bounds__(256, 1) gemm32_kernel(GemmP p) {
     auto rd = [&](auto kc, double& av, double (&bv)[4]) {
       constexpr int k4 = decltype(kc)::value;
       av = ds_read64<(LA == K_CONTIG ? 4 * k4 : 4 * k4 * LDA) * 8>(aA);
-      gfor<0, 4>([&](auto jc) {
+      static_for<0, 4>([&](auto jc) {
         constexpr int bc = decltype(jc)::value;
         bv[bc] = ds_read64<(LB == K_CONTIG ? 4 * bc * LDB + 4 * k4 : 4 * k4 * LDB + 4 * bc) * 8>(aB);
       });
     };
-    rd(GIC<0>{}, a[0], b[0]);
-    gfor<0, SKC / 4>([&](auto kc) {
+    rd(IC<0>{}, a[0], b[0]);
+    static_for<0, SKC / 4>([&](auto kc) {
       constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
-      if constexpr (k4 + 1 < SKC / 4) { rd(GIC<k4 + 1>{}, a[cur ^ 1], b[cur ^ 1]); lgkm_wait<5>(); }
+      if constexpr (k4 + 1 < SKC / 4) { rd(IC<k4 + 1>{}, a[cur ^ 1], b[cur ^ 1]); lgkm_wait<5>(); }
       else lgkm_wait<0>();
 #pragma unroll
       for (int bc = 0; bc < 4; ++bc) mfma444_acc(acc[bc], a[cur], b[cur][bc]);

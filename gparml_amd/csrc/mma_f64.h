@@ -20,6 +20,13 @@
 
 namespace gp {
 
+// compile-time loop: f(IC<B>{}), ..., f(IC<E-1>{}) -- the index is a constant expression inside f (immediate offsets, register arrays)
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
+
 constexpr int TILE = 128;          // workgroup output tile (rows and cols), 4 waves as 2x2 of 64x64
 constexpr int WT = 64;             // wave tile
 constexpr int KC = 16;             // k-chunk staged through LDS per iteration

@@ -21,12 +21,6 @@ namespace gp {
 struct P1Job { int kind; int acol; int bcol; int c0; int c1; int out; int pad0; int pad1; };   // kind: -1 idle, 0 F, 1 G
 struct P1v2Args { const double* Kaug; long ld; const P1Job* jobs; double* part; };
 
-template <int I> struct PIC { static constexpr int value = I; };
-template <int B, int E, typename F>
-__device__ __forceinline__ void pfor(F&& f) {
-  if constexpr (B < E) { f(PIC<B>{}); pfor<B + 1, E>(f); }
-}
-
 using LdsTiles = double[2][2][TILE_LDS_DOUBLES];
 
 // both operand tiles of one k-chunk: 16 LDS-DMA instructions per tile, two per wave (FREE_CONTIG rows of 128 doubles)
@@ -62,12 +56,12 @@ __device__ __forceinline__ void p1v2_full(const P1v2Args& p, const P1Job& jb, Ld
     if (c + 1 < nc) p1v2_dma(lds, cur ^ 1, Ab + (long)(c + 1) * step, Bb + (long)(c + 1) * step, p.ld, wave, lane);
     const unsigned aA = lds_byte_addr(lds[cur][0]) + 8u * (unsigned)aofs;
     const unsigned aB = lds_byte_addr(lds[cur][1]) + 8u * (unsigned)bofs;
-    pfor<0, KC / 4>([&](auto k4c) {
+    static_for<0, KC / 4>([&](auto k4c) {
       constexpr int k4 = decltype(k4c)::value;
       double a[4], b[8];
-      pfor<0, 4>([&](auto ic) { constexpr int ar = decltype(ic)::value; a[ar] = ds_read64<k4 * 4 * LDS_RC * 8 + 128 * ar>(aA); });
-      pfor<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<k4 * 4 * LDS_RC * 8 + 32 * j>(aB); });
-      pfor<0, 8>([&](auto jc) {
+      static_for<0, 4>([&](auto ic) { constexpr int ar = decltype(ic)::value; a[ar] = ds_read64<k4 * 4 * LDS_RC * 8 + 128 * ar>(aA); });
+      static_for<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<k4 * 4 * LDS_RC * 8 + 32 * j>(aB); });
+      static_for<0, 8>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         lgkm_wait<7 - j>();
 #pragma unroll
@@ -120,18 +114,18 @@ __device__ __forceinline__ void p1v2_diag(const P1v2Args& p, const P1Job& jb, Ld
     const unsigned rowop = lds_byte_addr(lds[cur][0]) + 8u * (unsigned)(lk * LDS_RC + lr);   // A-operand view of the K tile (16 rows of the output)
     const unsigned colK = lds_byte_addr(lds[cur][0]) + 8u * (unsigned)(lk * LDS_RC + lj);    // B-operand view of the SAME tile (4 output columns)
     const unsigned colY = lds_byte_addr(lds[cur][1]) + 8u * (unsigned)(lk * LDS_RC + lj);    // B-operand view of the Y tile
-    pfor<0, KC / 4>([&](auto k4c) {
+    static_for<0, KC / 4>([&](auto k4c) {
       constexpr int k4 = decltype(k4c)::value;
       constexpr int KO = k4 * 4 * LDS_RC * 8;
       const double a1 = ds_read64<KO + 128 * A1>(rowop);
       const double a2 = ds_read64<KO + 128 * A2>(rowop);
       if constexpr (H == 0) {
-        pfor<0, (32 - B1 + 7) / 8>([&](auto gc) {
+        static_for<0, (32 - B1 + 7) / 8>([&](auto gc) {
           constexpr int b0 = B1 + 8 * decltype(gc)::value;
           constexpr int nb = (32 - b0) < 8 ? (32 - b0) : 8;
           double b[nb];
-          pfor<0, nb>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<KO + 32 * (b0 + j)>(colK); });
-          pfor<0, nb>([&](auto jc) {
+          static_for<0, nb>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<KO + 32 * (b0 + j)>(colK); });
+          static_for<0, nb>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             lgkm_wait<nb - 1 - j>();
             mfma444_acc(acc1[b0 + j - B1], a1, b[j]);
@@ -139,21 +133,21 @@ __device__ __forceinline__ void p1v2_diag(const P1v2Args& p, const P1Job& jb, Ld
           });
         });
         if constexpr (Y0 > 0) {
-          pfor<0, (Y0 + 7) / 8>([&](auto gc) {
+          static_for<0, (Y0 + 7) / 8>([&](auto gc) {
             constexpr int y0 = 8 * decltype(gc)::value;
             constexpr int ny = (Y0 - y0) < 8 ? (Y0 - y0) : 8;
             double y[ny];
-            pfor<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; y[j] = ds_read64<KO + 32 * (y0 + j)>(colY); });
-            pfor<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; lgkm_wait<ny - 1 - j>(); mfma444_acc(acc3[y0 + j], a1, y[j]); });
+            static_for<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; y[j] = ds_read64<KO + 32 * (y0 + j)>(colY); });
+            static_for<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; lgkm_wait<ny - 1 - j>(); mfma444_acc(acc3[y0 + j], a1, y[j]); });
           });
         }
       } else {
-        pfor<0, (NBY + 7) / 8>([&](auto gc) {
+        static_for<0, (NBY + 7) / 8>([&](auto gc) {
           constexpr int y0 = 8 * decltype(gc)::value;
           constexpr int ny = (NBY - y0) < 8 ? (NBY - y0) : 8;
           double y[ny];
-          pfor<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; y[j] = ds_read64<KO + 32 * (y0 + j)>(colY); });
-          pfor<0, ny>([&](auto jc) {
+          static_for<0, ny>([&](auto jc) { constexpr int j = decltype(jc)::value; y[j] = ds_read64<KO + 32 * (y0 + j)>(colY); });
+          static_for<0, ny>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             lgkm_wait<ny - 1 - j>();
             mfma444_acc(acc2[y0 + j], a2, y[j]);

@@ -2,6 +2,7 @@
 // times its phases through POTRF_STAMP).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "mma_f64.h"
 
 #ifndef POTRF_STAMP
 #define POTRF_STAMP(i)
@@ -27,12 +28,6 @@ constexpr int NB = 128;  // panel width = GEMM tile
 // The earlier pair (register-blocked factorisation with two workgroup barriers per 4-column step + a VALU inverse over LDS
 // dot products) took 59 + 36 us per block.
 constexpr int PLD = NB + 2;
-
-template <int I> struct PIC { static constexpr int value = I; };
-template <int B, int E, typename F>
-__device__ __forceinline__ void pfor(F&& f) {
-  if constexpr (B < E) { f(PIC<B>{}); pfor<B + 1, E>(f); }
-}
 
 // LDS-only synchronisation: wait for this wave's LDS operations, not for its global stores (a workgroup-scope fence or
 // __syncthreads() also waits for vmcnt(0), i.e. 1-2 us behind every batch of stores of L to global memory)
@@ -144,7 +139,7 @@ __global__ void __launch_bounds__(512) potrf_trinv128_kernel(double* A, long ld,
         a[2 * p] = v.x; a[2 * p + 1] = v.y;
       }
       double myinv = 1.0, mydiag = 1.0;
-      pfor<0, 32>([&](auto jc) {
+      static_for<0, 32>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const double d = readlane_f64(a[j], j);
         if (!(d > 0.0)) bad = fmax(bad, d == 0.0 ? 2.0 : 1.0);     // no repair: the flagged factor is never used (linalg.hip: check_global)
@@ -152,7 +147,7 @@ __global__ void __launch_bounds__(512) potrf_trinv128_kernel(double* A, long ld,
         const double l = a[j] * inv;
         a[j] = l;
         if (i == j) { myinv = inv; mydiag = l; }
-        pfor<j + 1, 32>([&](auto kc) {
+        static_for<j + 1, 32>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           a[k] = fma(-l, readlane_f64(l, k), a[k]);
         });
@@ -187,10 +182,10 @@ __global__ void __launch_bounds__(512) potrf_trinv128_kernel(double* A, long ld,
           for (int p = 0; p < (i + 1) / 2; ++p) b[p] = *reinterpret_cast<const double2*>(Ls + i * PLD + 2 * p);
           d = Tl[i];
         };
-        load_row(PIC<0>{}, row[0], dinv[0]);
-        pfor<0, 16>([&](auto ic) {
+        load_row(IC<0>{}, row[0], dinv[0]);
+        static_for<0, 16>([&](auto ic) {
           constexpr int i = decltype(ic)::value, cur = i & 1;
-          if constexpr (i + 1 < 16) load_row(PIC<i + 1>{}, row[cur ^ 1], dinv[cur ^ 1]);
+          if constexpr (i + 1 < 16) load_row(IC<i + 1>{}, row[cur ^ 1], dinv[cur ^ 1]);
           __builtin_amdgcn_sched_barrier(0);
           double s0 = (cl == i) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
@@ -306,8 +301,8 @@ __global__ void __launch_bounds__(512) potrf_trinv128_kernel(double* A, long ld,
     }
     block_sync_lds();
   };
-  level(PIC<32>{});
-  level(PIC<64>{});
+  level(IC<32>{});
+  level(IC<64>{});
   POTRF_STAMP(20);
   {
     // addresses from an opaque copy of the thread id: computed at kernel entry they were spilled, and every reload here waited

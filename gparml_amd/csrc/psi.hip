@@ -8,11 +8,6 @@
 
 namespace gp {
 
-template <int I> struct IC { static constexpr int value = I; };
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
-}
 
 // ------------------------------------------------------------------------------------------------ Y upload
 // Kaug[n][Mp + d] = Y[n][d] (zero padded); one block per row group

@@ -14,12 +14,6 @@
 
 namespace gp {
 
-template <int I> struct B2IC { static constexpr int value = I; };
-template <int B, int E, typename F>
-__device__ __forceinline__ void b2for(F&& f) {
-  if constexpr (B < E) { f(B2IC<B>{}); b2for<B + 1, E>(f); }
-}
-
 // ---------------------------------------------------------------------------------------------- tables
 // per-point tables and LE in both layouts; thread = point for LET (coalesced along n), thread = column for LE
 __global__ void __launch_bounds__(256) b_tables_kernel(const double* __restrict__ mu, const double* __restrict__ S,
@@ -259,14 +253,14 @@ __global__ void __launch_bounds__(256, 2) psi2_pairs_mfma_kernel(const double* _
       double av[2][4], bv[2][4];
       auto rd = [&](auto kc, double (&a_)[4], double (&b_)[4]) {
         constexpr int k4 = decltype(kc)::value;
-        b2for<0, 4>([&](auto rc) { constexpr int rb = decltype(rc)::value; a_[rb] = ds_read64<(16 * rb * LDZ + 4 * k4) * 8>(aA); });
-        b2for<0, 4>([&](auto cc) { constexpr int cq = decltype(cc)::value; b_[cq] = ds_read64<(4 * cq * LDZ + 4 * k4) * 8>(aB); });
+        static_for<0, 4>([&](auto rc) { constexpr int rb = decltype(rc)::value; a_[rb] = ds_read64<(16 * rb * LDZ + 4 * k4) * 8>(aA); });
+        static_for<0, 4>([&](auto cc) { constexpr int cq = decltype(cc)::value; b_[cq] = ds_read64<(4 * cq * LDZ + 4 * k4) * 8>(aB); });
       };
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own ZZ_n stores above have landed
-      rd(B2IC<0>{}, av[0], bv[0]);
-      b2for<0, NQ>([&](auto kc) {
+      rd(IC<0>{}, av[0], bv[0]);
+      static_for<0, NQ>([&](auto kc) {
         constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
-        if constexpr (k4 + 1 < NQ) { rd(B2IC<k4 + 1>{}, av[cur ^ 1], bv[cur ^ 1]); lgkm_wait<8>(); }
+        if constexpr (k4 + 1 < NQ) { rd(IC<k4 + 1>{}, av[cur ^ 1], bv[cur ^ 1]); lgkm_wait<8>(); }
         else lgkm_wait<0>();
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
@@ -632,13 +626,13 @@ __global__ void __launch_bounds__(256, 2) psi2_cols_mfma_kernel(PB2Args a, const
         double av[2][RB], bv[2][4];
         auto rd = [&](auto kc, double (&a_)[RB], double (&b_)[4]) {
           constexpr int k4 = decltype(kc)::value;
-          b2for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; a_[rb] = ds_read64<(16 * rb * LDZ + 4 * k4) * 8>(aA); });
-          b2for<0, 4>([&](auto cc) { constexpr int cq = decltype(cc)::value; b_[cq] = ds_read64<(4 * cq * LDZ + 4 * k4) * 8>(aB); });
+          static_for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; a_[rb] = ds_read64<(16 * rb * LDZ + 4 * k4) * 8>(aA); });
+          static_for<0, 4>([&](auto cc) { constexpr int cq = decltype(cc)::value; b_[cq] = ds_read64<(4 * cq * LDZ + 4 * k4) * 8>(aB); });
         };
-        rd(B2IC<0>{}, av[0], bv[0]);
-        b2for<0, NQ>([&](auto kc) {
+        rd(IC<0>{}, av[0], bv[0]);
+        static_for<0, NQ>([&](auto kc) {
           constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
-          if constexpr (k4 + 1 < NQ) { rd(B2IC<k4 + 1>{}, av[cur ^ 1], bv[cur ^ 1]); lgkm_wait<RB + 4>(); }
+          if constexpr (k4 + 1 < NQ) { rd(IC<k4 + 1>{}, av[cur ^ 1], bv[cur ^ 1]); lgkm_wait<RB + 4>(); }
           else lgkm_wait<0>();
 #pragma unroll
           for (int rb = 0; rb < RB; ++rb)
@@ -663,15 +657,15 @@ __global__ void __launch_bounds__(256, 2) psi2_cols_mfma_kernel(PB2Args a, const
         double b2[2][RB];
         auto rd2 = [&](auto qc, double (&b_)[RB]) {
           constexpr int qq = decltype(qc)::value;
-          b2for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; b_[rb] = ds_read64<(16 * rb * LDZ + 4 * qq) * 8>(aB2); });
+          static_for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; b_[rb] = ds_read64<(16 * rb * LDZ + 4 * qq) * 8>(aB2); });
         };
-        rd2(B2IC<0>{}, b2[0]);
+        rd2(IC<0>{}, b2[0]);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc_fence<4>(E[rb]);
         asm volatile("s_nop 4");
-        b2for<0, NQ>([&](auto qc) {
+        static_for<0, NQ>([&](auto qc) {
           constexpr int qq = decltype(qc)::value, cur = qq & 1;
-          if constexpr (qq + 1 < NQ) { rd2(B2IC<qq + 1>{}, b2[cur ^ 1]); lgkm_wait<RB>(); }
+          if constexpr (qq + 1 < NQ) { rd2(IC<qq + 1>{}, b2[cur ^ 1]); lgkm_wait<RB>(); }
           else lgkm_wait<0>();
 #pragma unroll
           for (int rb = 0; rb < RB; ++rb)

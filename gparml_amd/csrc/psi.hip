@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
 // Kaug[n][m] = exp(ln c1_n - 1/2 sum_q u_nq (mu_nq - z_mq)^2), u = alpha/(alpha S + 1)   (kernel_exp.py:80)
 // z_m lives in registers (QP = Q rounded up to 2, zero padded); the packed per-point records PU[n] = [mu_n | u_n | ln c1_n]
 // (written by the prep kernels) are staged through LDS; no guards in the q loop (padding has u = 0).
-constexpr int PSI1_ROWS = 128;   // rows per workgroup of psi1_kernel (Np is a multiple of 128)
+constexpr int PSI1_ROWS = 128;   // row granule of psi1_kernel (Np is a multiple of 128); a workgroup takes `nblk` granules
 // FIXA (fixed embeddings, every variance zero): u_nq = alpha_q and ln c1 = ln sf2 for every point, so the records carry only
 // sqrt(alpha) o mu (scaled while they are staged), z is scaled once per lane and the exponent is -1/2 sum_q (mu' - z')^2:
 // 2 Q + 18 issue slots per element instead of 3 Q + 20, and nothing per point depends on the hyper-parameters (the prep
@@ -111,7 +111,7 @@ constexpr int PSI1_ROWS = 128;   // rows per workgroup of psi1_kernel (Np is a m
 template <int QP, bool FIXA>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                    long N, long Np, int M, int Mp, int Q, long ld, int WC, const double* __restrict__ alpha,
-                                                   double lnsf2) {
+                                                   double lnsf2, int nblk) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
   // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
   // [mu | u | lnc1] records are staged in LDS (below).
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   // (4 / WC)-th row of a 16-row group instead of idling: M = 128 ran at a quarter of the rate)
   const int RG = 4 / WC, rg = wave / WC;
   const int col = (blockIdx.x * WC + (wave % WC)) * 128 + 2 * lane;
-  const long row0 = blockIdx.y * (long)PSI1_ROWS;
+  const long row0 = blockIdx.y * (long)PSI1_ROWS * nblk;      // nblk granules per workgroup: the per-lane set-up (z, sqrt(alpha)) is paid once
   const bool ok0 = col < M, ok1 = col + 1 < M;
   const ExpTab xt = exp_tab_lane();
   double z0[QP], z1[QP];
@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   // Records of 16 rows at a time: one coalesced load into LDS, read back as broadcast operands; the next group's records
   // travel while the current group is computed.  (Per-row scalar loads cost a serial memory round trip per row and held the
   // kernel at 1.9 ms although plain stores reach 5.5 TB/s: tools/ubench/store_ubench.hip.)
-  constexpr int GR = 16, NG = PSI1_ROWS / GR, RPT = (GR * WS + 255) / 256;
+  constexpr int GR = 16, RPT = (GR * WS + 255) / 256;
+  const int NG = (int)min((long)nblk * (PSI1_ROWS / GR), (Np - row0) / GR);   // Np is a multiple of 128: whole groups only
   __shared__ double rec_s[2][GR * WS];
   double stage[RPT];
   auto fetch = [&](int g, int i) -> double {
@@ -337,13 +338,14 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 template <int QP>
 static void launch_psi1(gp_ctx* c, bool fixa) {
   const int WC = c->Mp >= 512 ? 4 : (c->Mp >= 256 ? 2 : 1);
-  dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)(c->Np / PSI1_ROWS));
+  const int nblk = c->Np >= (1L << 17) ? 4 : 1;                  // 512 rows per workgroup on large shards (still >= 7 workgroups per CU at N = 1e6)
+  dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)((c->Np / PSI1_ROWS + nblk - 1) / nblk));
   if (fixa)
     hipLaunchKernelGGL((psi1_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                       (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2));
+                       (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk);
   else
     hipLaunchKernelGGL((psi1_kernel<QP, false>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                       (long)c->LDK, WC, (const double*)c->alpha, 0.0);
+                       (long)c->LDK, WC, (const double*)c->alpha, 0.0, nblk);
 }
 
 int run_prep_and_generate(gp_ctx* c) {

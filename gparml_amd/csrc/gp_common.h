@@ -12,6 +12,8 @@
 namespace gp {
 
 inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+// latent width of the packed per-point records of psi1_kernel (Q <= 16: Q rounded up to 2) / psi1_wide_kernel (24, 32, 52, 64); 0: none
+inline int psi1_qp(int Q) { return Q <= 16 ? (Q + 1) / 2 * 2 : Q <= 24 ? 24 : Q <= 32 ? 32 : Q <= 52 ? 52 : Q <= 64 ? 64 : 0; }
 
 // dense batched GEMM on tile-aligned buffers: C = alpha * op(A) op(B) + beta * C
 struct GemmP {

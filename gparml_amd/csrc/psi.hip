@@ -187,6 +187,68 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   }
 }
 
+// Wide latent spaces (17 <= Q <= 64, records padded to QP = 24 / 32 / 52 / 64): the same kernel with ONE column per lane (z_m is QP
+// registers) and four waves = 256 columns per workgroup.  Replaces the generic fallback there (per-element global loads and libm exp:
+// 1.8 ms per 2e4 x 1024 at Q = 50 against 0.1 ms of arithmetic).
+template <int QP, bool FIXA>
+__global__ void __launch_bounds__(256) psi1_wide_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
+                                                        long N, long Np, int M, int Mp, int Q, long ld, const double* __restrict__ alpha,
+                                                        double lnsf2, int nblk) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = (blockIdx.x * 4 + wave) * 64 + lane;
+  const long row0 = blockIdx.y * (long)PSI1_ROWS * nblk;
+  const bool ok = col < M;
+  const ExpTab xt = exp_tab_lane();
+  double z[QP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const double sa = (FIXA && q < Q) ? sqrt(alpha[q]) : 1.0;
+    z[q] = (q < Q && ok) ? sa * Z[(long)col * Q + q] : 0.0;
+  }
+  constexpr int W = 2 * QP + 2, WS = FIXA ? QP : W;
+  constexpr int GR = 16, RPT = (GR * WS + 255) / 256;
+  const int NG = (int)min((long)nblk * (PSI1_ROWS / GR), (Np - row0) / GR);
+  __shared__ double rec_s[2][GR * WS];
+  double stage[RPT];
+  auto fetch = [&](int g, int i) -> double {
+    const int e = threadIdx.x + 256 * i;
+    if (e >= GR * WS) return 0.0;
+    if (!FIXA) return PU[(row0 + GR * g) * W + e];
+    const int r = e / QP, q = e - r * QP;
+    return (q < Q ? sqrt(alpha[q]) : 0.0) * PU[(row0 + GR * g + r) * W + q];
+  };
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * WS) rec_s[0][e] = fetch(0, i); }
+  __syncthreads();
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) stage[i] = fetch(g + 1, i);
+    }
+    const double* recs = rec_s[g & 1];
+#pragma unroll 1
+    for (int r = 0; r < GR; ++r) {
+      const long n = row0 + GR * g + r;
+      const double* row = recs + r * WS;
+      double e0 = 0.0, e1 = 0.0;               // two partial sums: the chain of QP dependent FMAs is the latency here
+#pragma unroll
+      for (int q = 0; q < QP; q += 2) {
+        const double d0 = row[q] - z[q], d1 = row[q + 1] - z[q + 1];
+        if (FIXA) { e0 = fma(d0, d0, e0); e1 = fma(d1, d1, e1); }
+        else { e0 = fma(row[QP + q] * d0, d0, e0); e1 = fma(row[QP + q + 1] * d1, d1, e1); }
+      }
+      const double x = fexp_t(fma(-0.5, e0 + e1, FIXA ? lnsf2 : row[2 * QP]), xt);   // all lanes, then select
+      if (col < Mp) Kaug[n * ld + col] = (n < N && ok) ? x : 0.0;
+    }
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * WS) rec_s[(g + 1) & 1][e] = stage[i]; }
+    }
+    __syncthreads();
+  }
+}
+
 // generic fallback (any Q): operands from global memory
 __global__ void __launch_bounds__(256) psi1_generic_kernel(const double* __restrict__ mu, const double* __restrict__ U,
                                                            const double* __restrict__ lnc1, const double* __restrict__ Z,
@@ -348,13 +410,25 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
                        (long)c->LDK, WC, (const double*)c->alpha, 0.0, nblk);
 }
 
+template <int QP>
+static void launch_psi1_wide(gp_ctx* c, bool fixa) {
+  const int nblk = c->Np >= (1L << 17) ? 4 : 1;
+  dim3 grid((c->Mp + 255) / 256, (unsigned)((c->Np / PSI1_ROWS + nblk - 1) / nblk));
+  if (fixa)
+    hipLaunchKernelGGL((psi1_wide_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                       (long)c->LDK, (const double*)c->alpha, log(c->sf2), nblk);
+  else
+    hipLaunchKernelGGL((psi1_wide_kernel<QP, false>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                       (long)c->LDK, (const double*)c->alpha, 0.0, nblk);
+}
+
 int run_prep_and_generate(gp_ctx* c) {
   PrepArgs a;
   a.Xmu = c->Xmu; a.Xs = c->Xs; a.dir = c->have_dir ? c->dir : nullptr; a.alpha = c->alpha;
   a.mu = c->mu; a.S = c->S; a.U = c->U; a.lnc1 = c->lnc1; a.Xa = c->Xa; a.klpart = c->klpart;
   a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CXp = c->CXp; a.step = c->step; a.sf2 = c->sf2;
   a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = p2_fast_mode(c) ? 1 : 0;
-  a.QP = (c->Q + 1) / 2 * 2; a.PU = a.QP <= 16 ? c->PU : nullptr;
+  a.QP = psi1_qp(c->Q); a.PU = a.QP > 0 ? c->PU : nullptr;
   // Fixed embeddings with every variance zero (regime A, no embedding gradients): the trial point is X_mu itself, S = 0, the
   // feature matrix is [mu | 1] and KL = 0 -- nothing the prep kernels write depends on the hyper-parameters, so they run once per
   // upload / mode switch; Psi1 then takes alpha and sf2 as arguments (psi1_kernel<QP, true>).
@@ -366,8 +440,15 @@ int run_prep_and_generate(gp_ctx* c) {
   }
   c->prep_fixa_valid = fixa;
   (void)hipEventRecord(c->ev[8], c->stream);
-  const int QP = (c->Q + 1) / 2 * 2;
-  if (QP <= 16) {
+  const int QP = psi1_qp(c->Q);
+  if (QP > 16) {
+    switch (QP) {
+      case 24: launch_psi1_wide<24>(c, fixa); break;
+      case 32: launch_psi1_wide<32>(c, fixa); break;
+      case 52: launch_psi1_wide<52>(c, fixa); break;
+      default: launch_psi1_wide<64>(c, fixa); break;
+    }
+  } else if (QP > 0) {
     switch (QP) {
       case 2: launch_psi1<2>(c, fixa); break;
       case 4: launch_psi1<4>(c, fixa); break;

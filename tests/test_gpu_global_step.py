@@ -121,3 +121,44 @@ def test_repeated_evaluations_are_bit_identical(regime, emb):
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[3] == outs[0][3] and o[4] == outs[0][4]
         assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+
+
+def test_fixed_embedding_preparation_cache_follows_the_hyper_parameters():
+    """With fixed embeddings the per-point preparation runs once per upload and Psi1 takes alpha / sf2 as arguments: a second
+    evaluation at other hyper-parameters (and one after a new upload, and one after a switch to embedding gradients and back) must
+    equal a fresh context's."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import factorised as Fz
+    N, D, M, Q = 2500, 7, 140, 6
+    d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=21, zseed=22, alpha_value=0.5)
+    rs = np.random.RandomState(3)
+    hypers = [(d['Z'], d['sf2'], d['alpha'], d['beta']),
+              (d['Z'] + 0.01 * rs.randn(M, Q), 1.7, np.asarray(d['alpha']) * rs.uniform(0.5, 2.0, size=np.asarray(d['alpha']).shape), 4.0)]
+
+    def fresh(Y, X_mu, h, emb=False):
+        e = ShardEngine(N, D, M, Q)
+        e.upload_shard(Y, X_mu, d['X_S'])
+        e.set_globals(*h)
+        o = e.evaluate(emb)
+        e.close()
+        return o
+
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    X2 = d['X_mu'] + 0.1 * rs.randn(N, Q)
+    steps = [(d['X_mu'], hypers[0], False), (d['X_mu'], hypers[1], False), (d['X_mu'], hypers[1], True), (d['X_mu'], hypers[0], False),
+             (X2, hypers[0], False), (X2, hypers[1], False)]
+    cur = d['X_mu']
+    for X_mu, h, emb in steps:
+        if X_mu is not cur:
+            eng.upload_shard(d['Y'], X_mu, d['X_S'])
+            cur = X_mu
+        eng.set_globals(*h)
+        out = eng.evaluate(emb)
+        ref = fresh(d['Y'], X_mu, h, emb)
+        # rounding-level agreement only: which of the two Psi1 forms (fixed-embedding or general) phase 1 used depends on the mode of
+        # the PREVIOUS evaluation; a stale cache would be wrong in the leading digits
+        assert abs(out['F'] - ref['F']) <= 1e-10 * abs(ref['F'])
+        for k in ('grad_Z', 'grad_alpha'):
+            assert np.max(np.abs(out[k] - ref[k])) <= 1e-8 * np.max(np.abs(ref[k])), k
+    eng.close()

@@ -820,6 +820,9 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
   constexpr int XS = 4 * NRB;
   static_assert(4096 + TILE * XS <= 4608 + 1024, "Xa tile does not fit next to slab set A");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Static priority for the second-dispatched half of the workgroup: with both halves at priority 0 the younger waves lose the VALU / LDS
+  // issue arbitration in every k-chunk (MI355X_MICROARCH.md, "Two waves per SIMD", item 4); same-box A/B: 10.27 -> 10.14 ms
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int quad = wave & 3, half = wave >> 2;
   const int wr = quad >> 1, wc = quad & 1;
   const int wrow0 = wr * WT, wcol0 = wc * WT + 32 * half;

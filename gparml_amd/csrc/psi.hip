@@ -893,24 +893,31 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
       const int cur = (c + nc + 1) & 1;
-      if (c + 1 < nc) {
-        ++kc;
-        chunk_dma(lds + (cur ^ 1) * 4608, Ab + (long)kc * KC, Bb + (long)kc * KC * p.Mp);
-      } else {
-        // last chunk (computing from buf0): slab 0 of this wave and the tile's Xa rows into buf1 + extra
-        const Epi e0 = epi();
-        slab_dma(e0, Ab - (long)p.kbeg * KC + (long)wrow0 * p.ld + (long)mt * TILE + wcol0, 0, setA);
-        for (int I = wave; I < TILE * XS / 128; I += 8) {       // 128 doubles (64 x 16 B) per instruction
-          const int piece = I * 64 + lane;                      // 16-byte piece of the compact [128][XS] tile
-          const int row = piece / (XS / 2), c2 = piece - row * (XS / 2);
-          glds16(p.Xa + (n0 + row) * p.CXp + 2 * c2, xa_s + I * 128);
+      // the next chunk's staging (or, in the last chunk, the epilogue's first slab and feature rows) is requested by the first half of
+      // the workgroup before k-step 0 and by the second half before k-step 2: the two waves a SIMD hosts from this workgroup are
+      // then never in VMEM issue at the same time
+      auto issue_next = [&]() {
+        if (c + 1 < nc) {
+          ++kc;
+          chunk_dma(lds + (cur ^ 1) * 4608, Ab + (long)kc * KC, Bb + (long)kc * KC * p.Mp);
+        } else {
+          // last chunk (computing from buf0): slab 0 of this wave and the tile's Xa rows into buf1 + extra
+          const Epi e0 = epi();
+          slab_dma(e0, Ab - (long)p.kbeg * KC + (long)wrow0 * p.ld + (long)mt * TILE + wcol0, 0, setA);
+          for (int I = wave; I < TILE * XS / 128; I += 8) {       // 128 doubles (64 x 16 B) per instruction
+            const int piece = I * 64 + lane;                      // 16-byte piece of the compact [128][XS] tile
+            const int row = piece / (XS / 2), c2 = piece - row * (XS / 2);
+            glds16(p.Xa + (n0 + row) * p.CXp + 2 * c2, xa_s + I * 128);
+          }
         }
-      }
+      };
+      if (half == 0) issue_next();
       // operand reads as explicit ds_read_b64 (see mma_f64.h): 4 A + 8 B per k-step, MFMAs start as soon as A and the first B landed
       const unsigned sbase_b = lds_base + (unsigned)cur * (4608u * 8u);
       const unsigned aB = sbase_b + TILE_LDS_DOUBLES * 8 + 8u * (unsigned)ofs.b[0];
       static_for<0, KC / 4>([&](auto k4c) {
         constexpr int k4 = decltype(k4c)::value;
+        if constexpr (k4 == 2) { if (half == 1) issue_next(); }
         const unsigned aA = sbase_b + 8u * (unsigned)ofs.a[k4];
         double a[4], b[8];
         a[0] = ds_read64<0>(aA); a[1] = ds_read64<2048>(aA); a[2] = ds_read64<4096>(aA); a[3] = ds_read64<6144>(aA);

@@ -15,10 +15,10 @@ constexpr int NB = 128;  // panel width = GEMM tile
 // Cholesky factor AND inverse factor of the 128x128 diagonal block j of each matrix in the batch, in one launch with the block
 // resident in LDS (row stride 130: the 16 rows x {k, k+1} of an MFMA operand read fall on 32 distinct 8-byte slots).
 // The block is processed as 4 x 4 sub-blocks of 32:
-//   * wave 0 factors the 32x32 diagonal sub-block in registers (lane (li, lj) of an 8x8 grid owns a 4x4 piece; eight 4-column
-//     steps, wave-synchronous: no workgroup barrier on the serial chain; the 4x4 diagonal factor reaches the lanes of its column
-//     by v_readlane, the solved 4-column panel reaches the trailing pieces through LDS) and inverts it in place by forward
-//     substitution (lane = column, the column in registers, rows of L as prefetched broadcast reads);
+//   * wave 0 factors the 32x32 diagonal sub-block with one ROW per lane in registers (pivots and L_kj by v_readlane, 1/sqrt from
+//     v_rsq_f64 + a third-order correction: no LDS traffic, no divergence, no workgroup barrier on the serial chain) and inverts
+//     it in place (two 16x16 halves by forward substitution with the column in registers and the rows of L as prefetched
+//     broadcast reads, merged by two 16x16x16 MFMA tiles);
 //   * all eight waves solve the sub-blocks below it (L_is = A_is W_s^T) and apply the rank-32 update of the trailing
 //     sub-blocks as 16x16 tiles of 4x4x4 FP64 MFMAs fed from the LDS image;
 //   * the off-diagonal part of the inverse, X21 = -X22 (L21 X11) at sizes 32 and 64, is two more rounds of such tiles, in place

@@ -38,6 +38,66 @@ def synthetic(N, D, M, Q, seed, regime='A'):
     return dict(Y=Y, X_mu=X_mu, X_S=X_S, Z=Z, sf2=1.0, alpha=np.full(Q, 0.1), beta=10.0)
 
 
+TRUTH_BLOCKS = ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta')
+
+
+def input_checksums(d):
+    """The checksums tests/golden/make_hp_truth_large.py stores with its extended-precision truth (same formulas)."""
+    w = np.cos(np.arange(d['Y'].shape[0], dtype=np.float64))
+    return np.array([d['Y'].sum(), np.abs(d['Y']).sum(), w.dot(d['Y']).sum(), d['X_mu'].sum(), w.dot(d['X_mu']).sum(),
+                     d['Z'].sum(), np.abs(d['Z']).sum()])
+
+
+def truth_errors(d, out, N, D, M, Q, seed):
+    """Errors of this run's bound and gradients against the committed long-double truth of the SAME workload
+    (tests/golden/hp_truth_large_N<N>.npz, oracle/hp_truth.c), relative to each block's largest magnitude; None when there is no
+    truth for this shape / seed or the regenerated inputs do not reproduce its checksums."""
+    f = os.path.join(ROOT, 'tests', 'golden', 'hp_truth_large_N%d.npz' % N)
+    if not os.path.exists(f):
+        return None
+    z = np.load(f)
+    if (int(z['N']), int(z['D']), int(z['M']), int(z['Q']), int(z['seed'])) != (N, D, M, Q, seed):
+        return None
+    cs = input_checksums(d)
+    if not np.allclose(cs, z['input_checksums'], rtol=1e-11, atol=1e-9):      # sin() may differ in the last bit between hosts
+        return None
+    res = {'cond_A': float(z['cond_A']), 'cond_Kmm': float(z['cond_Kmm']),
+           'F_err_vs_truth': abs(out['F'] - float(z['truth_F'])) / abs(float(z['truth_F']))}
+    for k in TRUTH_BLOCKS:
+        t = np.asarray(z['truth_' + k])
+        res['%s_err_vs_truth' % k] = float(np.max(np.abs(np.asarray(out[k]) - t)) / np.max(np.abs(t)))
+        res['%s_err_float64_lu' % k] = float(z['err_lu_' + k])
+        res['%s_err_float64_cholesky' % k] = float(z['err_chol_' + k])
+    res['truth'] = 'tests/golden/hp_truth_large_N%d.npz (80-bit long double, own uncertainty %.1e on grad_Z)' % (N, float(z['truth_uncertainty'][1]))
+    return res
+
+
+def regime_b_extra(name, N, D, M, Q, device, steps=2):
+    """One free-embedding (Bayesian GPLVM, regime B) evaluation shape, timed OUTSIDE the headline region: ms per evaluation (HIP
+    events on the engine's stream), SURVEY.md 8(d)'s W_B = N M^2 (4Q + 10) and its fraction of the FP64 peak, the dominant kernels."""
+    from gparml_amd.engine import ShardEngine
+    d = synthetic(N, D, M, Q, seed=7, regime='B')
+    d['alpha'] = np.full(Q, min(0.1, 1.0 / Q))
+    eng = ShardEngine(N, D, M, Q, device=device)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    eng.evaluate(True)
+    tot = {}
+    for _ in range(steps):
+        out = eng.evaluate(True)
+        for k, v in eng.timings().items():
+            tot[k] = tot.get(k, 0.0) + v / steps
+    eng.close()
+    W_B = float(N) * M * M * (4.0 * Q + 10.0)
+    return {'workload': name, 'N': N, 'D': D, 'M': M, 'Q': Q, 'ms': tot['total_ms'], 'W_B_flop': W_B,
+            'achieved_tflops': W_B / (tot['total_ms'] * 1e-3) / 1e12, 'frac': W_B / (tot['total_ms'] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            'ms_per_1e6_points': tot['total_ms'] * 1e6 / N,
+            'kernel_ms': {'psi2_phase1 (Psi2 pair kernel)': round(tot['p1_kernel_ms'], 3), 'psi2_phase2 (T_n = Bbar o psi2_n kernel)': round(tot['p2_kernel_ms'], 3),
+                          'generate': round(tot['generate_ms'], 3), 'phase1': round(tot['phase1_ms'], 3), 'global': round(tot['global_ms'], 3),
+                          'phase2': round(tot['phase2_ms'], 3)},
+            'F': out['F']}
+
+
 def cpu_baseline(D, M, Q, N_full, budget_rows):
     """The oracle's CPU evaluation (kind "port": numpy/OpenBLAS restatement of the same path, oracle/factorised.py) on a bounded sample of
     the same workload, scaled linearly in N.  ``value`` is the BLAS-bound arrangement (evaluate_blas: K_nm kept between the phases, work
@@ -81,6 +141,7 @@ def main():
     ap.add_argument('--regime', choices=['A', 'B'], default='A',
                     help='A (default, the metric\'s configuration): X_S = 0, fixed embeddings; B: Bayesian GPLVM, X_S > 0, embedding gradients')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the regime-B shapes reported under "extra" (outside the timed region)')
     ap.add_argument('--cpu-rows', type=int, default=200000)
     a = ap.parse_args()
 
@@ -132,11 +193,15 @@ def main():
     barrier()
     t0 = time.time()
     kern = {'psi1_ms': 0.0, 'p1_kernel_ms': 0.0, 'p2_kernel_ms': 0.0, 'global_ms': 0.0, 'total_ms': 0.0}
+    ev.time_collectives = world > 1   # events around the two all-reduces (read back after the evaluation's own synchronisation)
+    coll = {'allreduce_stats_ms': 0.0, 'allreduce_grads_ms': 0.0}
     for _ in range(a.steps):
         out = ev.evaluate(emb)
         tm = eng.timings()            # HIP events on the engine's stream around each kernel of this evaluation
         for k in kern:
             kern[k] += tm[k]
+        for k, v in ev.collective_ms().items():
+            coll[k] += v
     barrier()
     dt = time.time() - t0
     if world > 1:
@@ -145,6 +210,8 @@ def main():
         dt = float(tt.item())
     for k in kern:
         kern[k] /= a.steps
+    for k in coll:
+        coll[k] /= a.steps
 
     if rank == 0:
         N, D, M, Q = a.N, a.D, a.M, a.Q
@@ -190,8 +257,27 @@ def main():
             res['config']['eval_fraction_of_fp64_peak'] = achB / FP64_PEAK_TFLOPS
             res['roofline'] = {'bound': 'mfma', 'kernel': 'whole evaluation (psi2 pair kernels, FP64 VALU/MFMA pipe)', 'achieved': achB,
                                'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achB / FP64_PEAK_TFLOPS, 'traffic': None}
+        if world > 1:
+            # what the N > 1 line needs to attribute a scaling loss: the two collectives and the replicated global step, per evaluation
+            res['config']['allreduce_ms'] = {k: round(v, 4) for k, v in coll.items()}
+            res['config']['allreduce_ms']['total'] = round(sum(coll.values()), 4)
+            res['config']['global_ms'] = round(kern['global_ms'], 4)
+        if a.regime == 'A':
+            # parity of THIS run's last evaluation against the extended-precision truth of the same workload (rank 0's shard alone:
+            # only meaningful for one shard), and the conditioning it was obtained at
+            te = truth_errors(d, out, N, D, M, Q, 100 + rank) if world == 1 else None
+            if te is not None:
+                res['config'].update({'cond_A': te['cond_A'], 'cond_Kmm': te['cond_Kmm'], 'grad_Z_err_vs_truth': te['grad_Z_err_vs_truth'],
+                                      'F_err_vs_truth': te['F_err_vs_truth'], 'parity_vs_truth': te})
         if not a.no_cpu_baseline and world == 1 and a.regime == 'A':     # rank 0 at N=1 only
             res['cpu_baseline'] = cpu_baseline(D, M, Q, N, min(a.cpu_rows, N))
+        if not a.no_extra and world == 1 and a.regime == 'A' and (N, D, M, Q) == (1000000, 100, 512, 10):
+            # regime B (free embeddings) is not the metric's configuration; two shapes, each a slice of a BASELINE config, measured after
+            # the timed region so that the driver's own run carries them
+            eng.close()
+            res['extra'] = [regime_b_extra('BASELINE configs[2] shape with free embeddings (Bayesian GPLVM), 1e5-point slice', 100000, 100, 512, 10, local_rank),
+                            regime_b_extra('BASELINE configs[4] per-GPU shape (D=1000, M=1024, Q=50, free embeddings), 2e4-point slice', 20000, 1000, 1024, 50,
+                                           local_rank)]
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -915,6 +915,8 @@ static void launch_pairs_mfma(gp_ctx* c, int S) {
 }
 
 int run_phase1_b(gp_ctx* c) {
+  // gp_last_timings' "p1 kernel" slot: in regime B the Psi2 pair kernel (the C tiles' p1_kernel8 launch recorded the events before)
+  (void)hipEventRecord(c->ev[10], c->stream);
   if (c->b_mfma) {
     // 64 x 64 tiles x n-slices: several rounds of workgroups over the 512 resident slots, >= 256 points per slice
     int S = (int)std::max<long>(1, std::min<long>(32, std::max<long>((2048 + c->n_tiles64 - 1) / c->n_tiles64, c->N / 4096)));
@@ -924,6 +926,7 @@ int run_phase1_b(gp_ctx* c) {
       case 52: launch_pairs_mfma<52>(c, S); break;
       default: launch_pairs_mfma<64>(c, S); break;
     }
+    (void)hipEventRecord(c->ev[11], c->stream);
     GP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(psi2_reduce64_kernel, dim3(c->n_tiles64), dim3(256), 0, c->stream, c->part, c->tiles64, c->n_tiles64, S, c->M, c->Mp, c->stats);
     GP_HIP(c, hipGetLastError());
@@ -942,6 +945,7 @@ int run_phase1_b(gp_ctx* c) {
     case 52: launch_pairs<52>(c, S); break;
     default: launch_pairs<64>(c, S); break;
   }
+  (void)hipEventRecord(c->ev[11], c->stream);
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_reduce_kernel, dim3(c->n_ptiles), dim3(256), 0, c->stream, c->part, c->ptiles, c->n_ptiles, S, c->M, c->Mp, c->stats);
   GP_HIP(c, hipGetLastError());
@@ -986,6 +990,7 @@ int run_phase2_b(gp_ctx* c) {
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
   a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb; a.ngrp = (c->nslab + std::min(4, c->nslab) - 1) / std::min(4, c->nslab);
+  (void)hipEventRecord(c->ev[12], c->stream);   // gp_last_timings' "p2 kernel" slot: in regime B the T_n = Bbar o psi2_n kernel
   if (c->b_mfma) {
     a.ngrp = c->nslab;
     int rc = GP_OK;
@@ -1009,6 +1014,7 @@ int run_phase2_b(gp_ctx* c) {
     case 52: launch_cols<52, false>(c, a); break;
     default: launch_cols<64, false>(c, a); break;
   }
+  (void)hipEventRecord(c->ev[13], c->stream);
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_points_finish_kernel, dim3((unsigned)std::min<long>(c->pb_blocks, 256)), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());

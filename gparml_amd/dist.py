@@ -39,6 +39,8 @@ class DistributedEvaluator(object):
         self._grads_t = None
         self.device = device
         self.force = force_collectives and dist.is_initialized()
+        self.time_collectives = False     # bench.py: device-side time of the two all-reduces of the last evaluation
+        self._cev = None
 
     def _tensors(self):
         if self._stats_t is None:
@@ -72,11 +74,16 @@ class DistributedEvaluator(object):
             if kept_fraction is None:
                 kept_fraction = float(sum(kept_mask)) / len(kept_mask)
         rescale = kept_fraction is not None and kept_fraction != 1.0
+        cev = self._collective_events() if (collective and self.time_collectives) else None
         eng.phase1()
         if not kept_here:
             eng.scale_buffer('stats', 0.0)
         if collective:
+            if cev:
+                cev[0].record()
             self.dist.all_reduce(stats_t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if cev:
+                cev[1].record()
         if rescale:
             eng.scale_buffer('stats', 1.0 / kept_fraction)
         jitter = 0
@@ -86,7 +93,11 @@ class DistributedEvaluator(object):
             if not kept_here:
                 eng.scale_buffer('grads', 0.0)
             if collective:
+                if cev:
+                    cev[2].record()
                 self.dist.all_reduce(grads_t, op=self.dist.ReduceOp.SUM, group=self.group)
+                if cev:
+                    cev[3].record()
             if rescale:
                 eng.scale_buffer('grads', 1.0 / kept_fraction)
             try:
@@ -95,6 +106,23 @@ class DistributedEvaluator(object):
                 # every rank holds the same reduced statistics and runs the same replicated global step, so all ranks take this
                 # branch together: repeat the global step with the reference's 1e-7 jitter (partial_terms.py:452-456)
                 jitter = r.mask
+
+
+    def _collective_events(self):
+        """Four timing events on torch's current stream (the stream the engine launches on and the collectives are ordered behind)."""
+        if self._cev is None:
+            import torch
+            self._cev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if torch.cuda.is_available() else False
+        return self._cev or None
+
+    def collective_ms(self):
+        """Device time of the two all-reduces of the last evaluation (0 when not timed).  With a stream-ordered backend (RCCL) the
+        events bracket the collective's kernels; with gloo they bracket its host-side staging copies."""
+        if not (self.time_collectives and self._cev):
+            return {'allreduce_stats_ms': 0.0, 'allreduce_grads_ms': 0.0}
+        import torch
+        torch.cuda.synchronize()
+        return {'allreduce_stats_ms': self._cev[0].elapsed_time(self._cev[1]), 'allreduce_grads_ms': self._cev[2].elapsed_time(self._cev[3])}
 
 
 def draw_kept_mask(n_nodes, drop_out_fraction, rng):

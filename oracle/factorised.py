@@ -84,15 +84,41 @@ def phase1(Z, sf2, alpha, Y, X_mu, X_S, chunk=4096):
 
 
 # ----------------------------------------------------------------------------------------- global step
-def global_step(Z, sf2, alpha, beta, stats, N_global, D, fixed_beta=False):
+def _global_step_lu(Z, s2, a, b, stats, N_global, D):
+    """The global step in the REFERENCE's own arrangement: LU ``inv`` of Kmm and of Kmm + beta Psi2 (partial_terms.py:60, 82, 95),
+    ``slogdet`` for the bound (:449-450), the partials as the products the reference forms (:102-131, 340-360) -- taken from the literal
+    restatement of the class (oracle/literal.py) fed with the summed statistics.  Used as the float64 "reference" column where the
+    imported reference itself cannot run (it stores an (N, M, M) tensor)."""
+    from . import literal
+    M, Q = Z.shape
+    pt = literal.PartialTermsOracle(Z, s2, a, b, M, Q, N_global, D)
+    pt.set_local_statistics(stats['sum_YYT'], stats['sum_exp_K_mi_K_im'], stats['exp_K_miY'], stats['sum_exp_K_ii'], stats['KL'])
+    return dict(F=pt.logmarglik(), Abar=pt.dF_dexp_K_miY(), Bbar=pt.dF_dexp_K_mi_K_im(), dF_dKmm=pt.dF_dKmm(), grad_beta=pt.grad_beta(),
+                Kmm=pt.Kmm, Kmm_inv=pt.Kmm_inv, Kmm_plus_op_inv=pt.Kmm_plus_op_inv)
+
+
+def global_step(Z, sf2, alpha, beta, stats, N_global, D, fixed_beta=False, linalg='cholesky'):
     """Replicated M x M algebra on the all-reduced statistics.
     [partial_terms.py:89-95 (Kmm), 54-61 (A^-1), 436-473 (F), 102-138 (partials), 340-360 (grad_beta),
-     146-160 / 247-254 / 306-308 (Kmm derivative parts), 322-333 (sf2 contraction)]"""
+     146-160 / 247-254 / 306-308 (Kmm derivative parts), 322-333 (sf2 contraction)]
+    ``linalg='lu'``: inverses, log-determinants and partials in the reference's LU arrangement (_global_step_lu)."""
     Z, s2, a, b = _as_params(Z, sf2, alpha, beta)
     M, Q = Z.shape
     Psi2, C = stats['sum_exp_K_mi_K_im'], stats['exp_K_miY']
     sum_YYT, Psi0, KL = stats['sum_YYT'], stats['sum_exp_K_ii'], stats['KL']
     dz = Z[:, None, :] - Z[None, :, :]
+    if linalg == 'lu':
+        lu = _global_step_lu(Z, s2, a, b, stats, N_global, D)
+        Kmm, Abar, Bbar, dF_dKmm = lu['Kmm'], lu['Abar'], lu['Bbar'], lu['dF_dKmm']
+        dF_dPsi0 = -0.5 * b * D
+        S = (dF_dKmm + dF_dKmm.T) * Kmm
+        gZ_K = -a[None, :] * (Z * S.sum(1)[:, None] - S.dot(Z))
+        V = dF_dKmm * Kmm
+        ga_K = -0.5 * np.einsum('ab,abq->q', V, dz * dz)
+        gs = (np.sum(V) + np.sum(Abar * C) + 2.0 * np.sum(Bbar * Psi2) + dF_dPsi0 * Psi0) / s2
+        return dict(F=lu['F'], Abar=Abar, Bbar=Bbar, dF_dKmm=dF_dKmm, dF_dPsi0=dF_dPsi0, grad_beta=0.0 if fixed_beta else lu['grad_beta'],
+                    grad_Z_K=gZ_K, grad_alpha_K=ga_K, grad_sf2=gs, Kmm=Kmm, Kmm_inv=lu['Kmm_inv'], Kmm_plus_op_inv=lu['Kmm_plus_op_inv'],
+                    BbarPsi2=Bbar * Psi2)
     Kmm = s2 * np.exp(-0.5 * np.sum(a[None, None, :] * dz * dz, axis=2))
     A = Kmm + b * Psi2
     try:
@@ -227,7 +253,7 @@ def synthetic_shard(N, D, M, Q, regime='A', seed=0, zseed=1, alpha_value=None):
 
 
 # ----------------------------------------------------------------------------------------- BLAS-bound CPU baseline
-def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixed_beta=False, work=None):
+def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixed_beta=False, work=None, linalg='cholesky'):
     """Regime A with fixed embeddings (X_S == 0, no per-point gradients) arranged so that the time goes into DGEMM: the same
     formulation as phase1 / global_step / phase2 / finish above, but K_nm is generated once per chunk and KEPT for phase 2 (the
     two-phase protocol regenerates it), the two back-propagation products are GEMMs on K and Y into one buffer, element-wise work is
@@ -265,8 +291,8 @@ def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixe
         C += E.T.dot(Yc)
         sum_YYT += float(np.einsum('ij,ij->', Yc, Yc))
     st = dict(sum_exp_K_mi_K_im=Psi2, exp_K_miY=C, sum_YYT=sum_YYT, sum_exp_K_ii=s2 * N_s, KL=0.0)
-    gs = global_step(Z, sf2, alpha, beta, st, Ng, D, fixed_beta)
-    B2 = 2.0 * gs['Bbar']
+    gs = global_step(Z, sf2, alpha, beta, st, Ng, D, fixed_beta, linalg=linalg)
+    B2 = np.ascontiguousarray(2.0 * gs['Bbar'].T)              # G[n, j] = sum_m' K[n, m'] 2 Bbar[j, m'] (partial_terms.py:238)
     At = np.ascontiguousarray(gs['Abar'].T)                     # G = K (2 Bbar) + Y Abar^T
     R1 = np.zeros((M, Q))
     R0 = np.zeros(M)

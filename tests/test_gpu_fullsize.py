@@ -94,17 +94,25 @@ def test_full_size_against_the_blas_port():
     kernel-spec port by tests/test_oracle_factorised.py).  Two hyper-parameter sets on the same data:
       alpha = 0.3: well conditioned -- measured F 3e-14, grad_Z 7e-10, the other gradients <= 1e-12 (relative to the block's
                    largest magnitude); asserted at 1e-9 / 1e-7;
-      alpha = 0.1: the benchmark's value -- cond(K_mm + beta Psi2) grows with N and grad_Z is a 70-fold cancellation (DESIGN.md
-                   section 6: two float64 CPU paths already differ by 8e-5 at N = 2e5), measured F 1e-11, grad_Z 2.8e-5,
-                   grad_alpha 6e-9, grad_sf2 4e-10, grad_beta 5e-13; asserted at 1e-8 for F, 2e-4 for grad_Z, 1e-6 for the rest."""
+      alpha = 0.1: the benchmark's value -- cond(K_mm + beta Psi2) = 1.4e10 and grad_Z amplifies the global step's rounding ~1000-fold.
+                   Two float64 evaluations cannot referee each other there, so the bound comes from the extended-precision truth of the
+                   benchmark workload (tests/test_hp_truth_large.py, tests/golden/hp_truth_large_N1000000.npz): the float64 Cholesky port is
+                   2.3e-5 from the truth on grad_Z and the reference's LU arrangement 8.9e-5, so two float64 paths may differ by their
+                   sum; asserted: grad_Z within err_lu + err_chol = 1.1e-4 of the port, F 1e-8, the other gradients 1e-6 (measured F 1e-11,
+                   grad_Z 2.8e-5, grad_alpha 6e-9, grad_sf2 4e-10, grad_beta 5e-13).  The device's own distance from the truth is asserted
+                   in tests/test_hp_truth_large.py."""
+    import os
+    from conftest import GOLDEN_DIR
     from gparml_amd.engine import ShardEngine
     from oracle import factorised as Fz
+    zt = np.load(os.path.join(GOLDEN_DIR, 'hp_truth_large_N1000000.npz'))
+    gz_bound = float(zt['err_lu_grad_Z']) + float(zt['err_chol_grad_Z'])
     N, D, M, Q = 1000000, 100, 512, 10
     d = _synthetic(N, D, M, Q, 'A')
     eng = ShardEngine(N, D, M, Q)
     eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
     work = {}
-    for alpha, f_tol, gz_tol, g_tol in ((0.3, 1e-9, 1e-7, 1e-7), (0.1, 1e-8, 2e-4, 1e-6)):
+    for alpha, f_tol, gz_tol, g_tol in ((0.3, 1e-9, 1e-7, 1e-7), (0.1, 1e-8, gz_bound, 1e-6)):
         al = np.full(Q, alpha)
         ref = Fz.evaluate_blas(d['Z'], d['sf2'], al, d['beta'], d['Y'], d['X_mu'], work=work)
         eng.set_globals(d['Z'], d['sf2'], al, d['beta'])

@@ -1,16 +1,31 @@
 #!/bin/bash
-# Build gparml_amd/libgparml_hip.so for gfx950 (in-tree). Usage: tools/build_lib.sh [--asm]
+# Build gparml_amd/libgparml_hip.so for gfx950 (in-tree).  Usage: tools/build_lib.sh [--asm]
+# Objects are cached per source under build/obj (rebuilt when the source or any header is newer) and compiled in parallel.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 SRC="$ROOT/gparml_amd/csrc"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
+OUT="${GPARML_LIB_OUT:-$ROOT/gparml_amd/libgparml_hip.so}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC ${GPARML_EXTRA_FLAGS}"
 if [ "$1" == "--asm" ]; then
   mkdir -p /tmp/asm
   for f in "$SRC"/*.hip; do
     b=$(basename "$f" .hip)
     (cd /tmp/asm && hipcc $FLAGS -c "$f" -save-temps=obj -o /tmp/asm/$b.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|Function Name|VGPRs:|AGPRs:|Spill:|ScratchSize|Occupancy|LDS Size" || true)
   done
-else
-  hipcc $FLAGS -shared "$SRC"/*.hip -o "$ROOT/gparml_amd/libgparml_hip.so" 2>&1 | grep -E "error|warning: v|Spill" || true
-  ls -la "$ROOT/gparml_amd/libgparml_hip.so"
+  exit 0
 fi
+OBJ="$ROOT/build/obj${GPARML_OBJ_TAG}"
+mkdir -p "$OBJ"
+newest_hdr=$(ls -t "$SRC"/*.h "$ROOT"/include/*.h | head -1)
+pids=()
+for f in "$SRC"/*.hip; do
+  o="$OBJ/$(basename "$f" .hip).o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then
+    rm -f "$o"
+    ( hipcc $FLAGS -c "$f" -o "$o" 2>&1 | grep -E "error|warning: v|Spill" || true; [ -f "$o" ] || { echo "FAILED: $f"; exit 1; } ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p || { echo "build failed"; exit 1; }; done
+hipcc --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
+ls -la "$OUT"

@@ -167,7 +167,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
                     c->HZp, c->gXmu, c->gXs, c->gapart, c->hgpart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
-                    c->Gpart, c->Gtmp, c->gapart2, c->pp, c->Z1S};
+                    c->Gpart, c->Gtmp, c->gapart2, c->pp, c->Z1S, c->ppt, c->Gt};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);
   if (c->ptiles) (void)hipFree(c->ptiles);

@@ -150,8 +150,13 @@ struct gp_ctx {
   int nslab = 0, ppb = 0;     // regime-B phase-2 pair kernel: 64-column slabs of M, points per workgroup
   int* ptiles = nullptr;      // upper-triangular 16x16 tile table for the psi2 pair kernel
   int n_ptiles = 0;
-  int* tiles64 = nullptr;     // upper-triangular 64x64 tile table for the MFMA pair kernel (wide latent spaces)
+  int* tiles64 = nullptr;     // upper-triangular 64x64 tile table for the MFMA pair kernel (wide latent spaces) and the tile-pair phase 2
   int n_tiles64 = 0;
+  // regime-B phase 2 on tile pairs (psi2_tile.hip, Q <= 51)
+  double* ppt = nullptr;      // [tiles][3Q+1][b_ch] per-point sums of every tile for the points of one launch
+  double* Gt = nullptr;       // [b_S][tiles][2][64][Q] grad_Z partials per workgroup
+  long b_ch = 0;              // points per launch
+  int b_S = 0;                // point slices per launch
   // CG vectors (resident): grad_latest/new/old (2,N,Q) each
   double* g_latest = nullptr;
   double* g_new = nullptr;
@@ -180,6 +185,9 @@ int run_generate_b(gp_ctx* c);
 int run_phase1_b(gp_ctx* c);
 int run_phase2_b(gp_ctx* c);
 int run_dz2(gp_ctx* c);
+// psi2_tile.hip (regime B phase 2 on tile pairs)
+bool pt2_applicable(const gp_ctx* c);
+int run_phase2_b_tiles(gp_ctx* c);
 // compat.hip
 int compat_build(gp_ctx* c, int which, double** out, long* count);
 // linalg.hip

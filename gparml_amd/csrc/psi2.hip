@@ -812,7 +812,8 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   c->ppb = (int)std::max<long>(16, (c->N + 4095) / 4096);
   c->pb_blocks = (int)((c->N + c->ppb - 1) / c->ppb);
   A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q); A(&c->Gtmp, (size_t)64 * M * Q);
-  A(&c->pp, (size_t)Np * (3 * c->QB + 1) * (c->b_mfma ? c->nslab : (c->nslab + 3) / 4));
+  // the tile-pair phase 2 (psi2_tile.hip) keeps its own per-launch buffer instead
+  A(&c->pp, pt2_applicable(c) ? 1 : (size_t)Np * (3 * c->QB + 1) * (c->b_mfma ? c->nslab : (c->nslab + 3) / 4));
   std::vector<int> t;
   const int Mt = (int)((M + 15) / 16);
   for (int i = 0; i < Mt; ++i) for (int j = i; j < Mt; ++j) { t.push_back(i); t.push_back(j); }
@@ -986,6 +987,7 @@ static int launch_cols_mfma(gp_ctx* c, const PB2Args& a) {
 
 int run_phase2_b(gp_ctx* c) {
   if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
+  if (pt2_applicable(c)) return run_phase2_b_tiles(c);
   PB2Args a;
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;

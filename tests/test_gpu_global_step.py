@@ -61,6 +61,78 @@ def test_jitter_retry_matches_the_reference_branch():
     eng.close()
 
 
+def _relmax(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(np.asarray(b))), 1e-300))
+
+
+def test_jitter_branch_gradients_against_the_restated_reference_branch():
+    """What the jitter branch does to the GRADIENTS.  The reference adds 1e-7*I only inside logmarglik (log-determinant and the trace
+    term, partial_terms.py:452-461); dF_dKmm / dF_dexp_K_miY / dF_dexp_K_mi_K_im / grad_beta keep Kmm_plus_op_inv = inv(Kmm + beta Psi2)
+    of the UN-jittered, here indefinite, matrix (:95, 102-131, 340-360).  The device path factorises by Cholesky, so it uses the inverse
+    of the jittered matrix everywhere (documented deviation, include/gparml_hip.h).  Two comparisons on the same inputs:
+      (a) against the reference's formulas with Kmm_plus_op_inv := inv(Kmm + beta Psi2 + 1e-7 I): the documented semantics, asserted;
+      (b) against the reference branch as it stands (oracle/literal.py, LU inverse of the indefinite matrix): the deviation itself,
+          measured and printed -- with the smallest eigenvalue at -5e-8 the two inverses differ by a sign flip of a 2e7-sized
+          eigen-direction, so the partials differ at O(1); the branch's gradients carry no information in the reference either."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import literal as L
+    d, (N, D, M, Q) = _setup()
+    st, Kmm = _indefinite_stats(d, 5e-8)
+    pt = L.PartialTermsOracle(d['Z'], d['sf2'], d['alpha'], d['beta'], M, Q, N, D)
+    pt.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+    ref = dict(dF_dKmm=pt.dF_dKmm(), Abar=pt.dF_dexp_K_miY(), Bbar=pt.dF_dexp_K_mi_K_im(), grad_beta=pt.grad_beta())
+    ptj = L.PartialTermsOracle(d['Z'], d['sf2'], d['alpha'], d['beta'], M, Q, N, D)
+    ptj.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+    ptj.Kmm_plus_op_inv = np.linalg.inv(Kmm + d['beta'] * st['Psi2'] + 1e-7 * np.eye(M))
+    # grad_beta's trace terms with the jittered inverse (partial_terms.py:340-360 restated, P := jittered inverse)
+    refj = dict(dF_dKmm=ptj.dF_dKmm(), Abar=ptj.dF_dexp_K_miY(), Bbar=ptj.dF_dexp_K_mi_K_im(), grad_beta=ptj.grad_beta())
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    eng.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+    eng.global_step()                                   # takes the retry internally
+    out = dict(dF_dKmm=eng.download('DF_DKMM'), Abar=eng.download('DF_DPSI1TY'), Bbar=eng.download('DF_DPSI2'), grad_beta=eng.scalars()['grad_beta'])
+    eng.close()
+    dev = {k: _relmax(out[k], ref[k]) for k in out}
+    print('jitter branch, device vs reference branch as it stands (LU inverse of the indefinite matrix):', {k: '%.2e' % v for k, v in dev.items()})
+    for k in out:
+        assert _relmax(out[k], refj[k]) <= 1e-5, (k, _relmax(out[k], refj[k]))
+        assert np.all(np.isfinite(out[k]))
+
+
+def test_coincident_and_nearly_coincident_inducing_points():
+    """The situations the reference's 1e-7 fallback was written for, with real statistics (no hand-made matrices).
+    (1) Two COINCIDENT inducing points: Kmm has two identical rows, the reference's linalg.inv raises "Singular matrix" before any
+        jitter applies (partial_terms.py:95); the device path meets an exactly zero Cholesky pivot and raises the same class.
+    (2) Two NEARLY coincident points (distance 1e-2, cond(Kmm) 3e7): neither path jitters; F agrees to 1e-6 and the gradients to the
+        1e-5 contract times the conditioning of this toy problem (the two float64 CPU paths, LU and Cholesky, differ by 1e-5 .. 4e-5
+        from each other here; measured device-vs-LU differences are printed).  Closer than that (1e-3: cond 3e9) the two CPU paths
+        already disagree by 5 % on grad_beta -- the reference's own numbers are noise there, with or without a jitter."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import literal as L
+    d, (N, D, M, Q) = _setup(seed=6, N=400, M=30)
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    Z = d['Z'].copy()
+    Z[1] = Z[0]
+    with pytest.raises(np.linalg.LinAlgError):
+        L.full_evaluation(Z, d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], with_embeddings=False)
+    eng.set_globals(Z, d['sf2'], d['alpha'], d['beta'])
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.evaluate(False)
+    Z[1] = Z[0] + 1e-2 * np.random.RandomState(0).randn(Q)
+    ref = L.full_evaluation(Z, d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], with_embeddings=False)
+    eng.set_globals(Z, d['sf2'], d['alpha'], d['beta'])
+    out = eng.evaluate(False)
+    eng.close()
+    diffs = {k: _relmax(out[k], ref[k]) for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta')}
+    print('nearly coincident inducing points (cond(Kmm) %.1e): F %.2e, gradients vs the LU path:' % (np.linalg.cond(ref['Kmm']), abs(out['F'] - ref['F']) / abs(ref['F'])),
+          {k: '%.2e' % v for k, v in diffs.items()})
+    assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F'])
+    for k, v in diffs.items():
+        assert v <= 2e-4, (k, v)
+
+
 def test_jitter_that_does_not_help_is_a_linalg_error():
     """Smallest eigenvalue -1e-6: still indefinite with 1e-7*I -> the reference's assertion (partial_terms.py:459-461) -> LinAlgError."""
     from gparml_amd.engine import ShardEngine

@@ -72,15 +72,26 @@ __device__ __forceinline__ double mul_asm(double a, double b) {   // ordered wit
   return r;
 }
 
+// first MFMA of an accumulation: C = 0 as an inline constant (no zeroing moves; "&": the result may not share a register with an operand)
+__device__ __forceinline__ void mfma444_zero(double& c, double a, double b) {
+  asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+
+// LDS image of the current point's tile for the two contractions: element (row, col) of T at tx[col * TXS + (row ^ 16 (col & 1))].
+// With TXS = 66 the column side's operand reads (16 columns x rows 4 s + {0, 1} per 32-lane group) are conflict-free and the row side's
+// (columns 4 s + {0, 1} x 16 rows) collide in 2 of 32 lanes.
+constexpr int TXS = 66;
+
 template <int QT>
 __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
-  constexpr int NQ = QT / 4, LDZ = QT + 2, TS = 65, RW = 3 * QT, NG = (NQ + 3) / 4;
+  constexpr int NQ = QT / 4, LDZ = QT + 2, RW = 3 * QT, NG = (NQ + 3) / 4;
   extern __shared__ double smem[];
   double* zr = smem;                          // [64][LDZ]  Z1 of slab I (rows of the tile)
   double* zj = zr + 64 * LDZ;                 // [64][LDZ]  Z1 of slab J (columns)
-  double* txb = zj + 64 * LDZ;                // [2 streams][64 cols][TS]  T^T of the current point
-  double* qtb = txb + 2 * 64 * TS;            // [2 streams][2 parities][3][QT]  v2 | alpha + w | 2 w mu
+  double* txb = zj + 64 * LDZ;                // [2 streams][64 * TXS]  the current point's tile
+  double* qtb = txb + 2 * 64 * TXS;           // [2 streams][2 parities][3][QT]  kappa | alpha + w | 2 w mu
   double* redb = qtb + 2 * 2 * 3 * QT;        // [2 streams][4 waves][RW]  per-wave s1 | s2 | s3
+  double* rrb = redb + 2 * 4 * RW;            // [8 waves][2 sides][16]  r of the wave's 16 columns / 16 rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, w = wave & 3, ts = tid & 255;
   const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4, lr = lane & 15;
@@ -95,69 +106,134 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
     zr[r * LDZ + q] = q < a.Q ? a.ZP[(64L * I + r) * a.QB + q] : one;
     zj[r * LDZ + q] = q < a.Q ? a.ZP[(64L * J + r) * a.QB + q] : one;
   }
-  double bb[4][4];     // Bbar[row 64 I + 16 rb + 4 lb + lk][col 64 J + 16 w + 4 cq + li]: the layout of the E / T registers
-#pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) bb[rb][cq] = a.Bbar[(64L * I + 16 * rb + 4 * lb + lk) * a.Mp + 64 * J + 16 * w + 4 * cq + li];
+  // Bbar[row 64 I + 16 rb + 4 lb + lk][col 64 J + 16 w + 4 cq + li] in the layout of the E / T registers: re-read (from the vector L1 / L2: the
+  // tile is 32 KB per workgroup) at the start of every phase A instead of being held in 32 VGPRs through phase B
+  const double* bbp = a.Bbar + (64L * I + 4 * lb + lk) * a.Mp + 64 * J + 16 * w + li;
   double Gc[NQ], Gr[NQ];   // grad_Z of (column 64 J + 16 w + 4 lb + lk | row 64 I + 16 w + 4 lb + lk), q = 4 qq + li, over this stream's points
 #pragma unroll
   for (int qq = 0; qq < NQ; ++qq) { Gc[qq] = 0.0; Gr[qq] = 0.0; }
-  double* tx = txb + g * (64 * TS);
+  double* tx = txb + g * (64 * TXS);
   double* red = redb + (g * 4 + w) * RW;
+  double* rr = rrb + wave * 32;
+  const int pofs = 16 * (li & 1), pk = 16 * (lk & 1);
   const unsigned aA = lds_byte_addr(zr) + 8u * (unsigned)(lr * LDZ + lk);                       // GEMM1 A: Z1_I[16 rb + lr][4 k4 + lk]
   const unsigned aB = lds_byte_addr(zj) + 8u * (unsigned)((16 * w + li) * LDZ + lk);            // GEMM1 B: Z1_J[16 w + 4 cq + li][4 k4 + lk]
-  const unsigned aB2 = lds_byte_addr(zr) + 8u * (unsigned)((4 * lb + lk) * LDZ + li);           // column side B: Z1_I[16 rb + 4 lb + lk][4 qq + li]
-  const unsigned aT = lds_byte_addr(tx) + 8u * (unsigned)(lk * TS + 16 * w + 4 * lb + li);      // row side A: T[16 w + 4 lb + li][4 cq' + lk]
-  const unsigned aZ = lds_byte_addr(zj) + 8u * (unsigned)(lk * LDZ + li);                       // row side B: Z1_J[4 cq' + lk][4 qq + li]
-  // ---- the next point's operands travel while the current point computes
-  double nlr[4], nlc[4], nq0 = 0.0, nq1 = 0.0, nq2 = 0.0;
+  // column side A: T[4 s + lk][16 w + 4 lb + li] (two bases: the row's bit 4 is flipped for odd columns); B: Z1_I[4 s + lk][4 qq + li]
+  const int cb = (16 * w + 4 * lb + li) * TXS + lk;
+  const unsigned aC0 = lds_byte_addr(tx) + 8u * (unsigned)(cb + pofs), aC1 = lds_byte_addr(tx) + 8u * (unsigned)(cb - pofs);
+  const unsigned aZc = lds_byte_addr(zr) + 8u * (unsigned)(lk * LDZ + li);
+  // row side A: T[16 w + 4 lb + li][4 s + lk]; B: Z1_J[4 s + lk][4 qq + li]
+  const unsigned aR = lds_byte_addr(tx) + 8u * (unsigned)(lk * TXS + ((16 * w + 4 * lb + li) ^ pk));
+  const unsigned aZr = lds_byte_addr(zj) + 8u * (unsigned)(lk * LDZ + li);
+  // tile store: reg (rb, cq) is T[16 rb + 4 lb + lk][16 w + 4 cq + li]
+  const int wb = (16 * w + li) * TXS + 4 * lb + lk;
+
+  // one side's contraction t[x][q] = sum over the 64 rows (COL) / columns (!COL) of the tile, result (x = 16 w + 4 lb + lk, q = 4 qq + li).
+  // Sixteen steps of NQ MFMAs (one A operand, NQ B operands).  Operands are requested RS steps ahead and every B register is re-requested
+  // right behind the MFMA that consumed it (the LDS return is at least an order of magnitude later than the MFMA's operand read), so
+  // RS * NQ + RS + 1 operand registers cover >= 128 cycles of MFMA issue per LDS round trip for every QT; RS is as deep as the 4-bit
+  // lgkmcnt allows.  Issue order: ..., M(s,0), A(s+RS), B(s+RS,0), M(s,1), B(s+RS,1), ...
+  auto contract = [&](auto colc, double (&tq)[NQ]) {
+    constexpr bool COL = decltype(colc)::value != 0;
+    constexpr int RS = 1 + (15 - NQ) / (NQ + 1);
+    double ta[RS + 1], bz[RS][NQ];
+    auto rdA = [&](auto sc) {
+      constexpr int s = decltype(sc)::value, slot = s % (RS + 1);
+      if constexpr (COL) ta[slot] = ((s >> 2) & 1) ? ds_read64<(4 * s) * 8>(aC1) : ds_read64<(4 * s) * 8>(aC0);
+      else ta[slot] = ds_read64<(4 * s * TXS) * 8>(aR);
+    };
+    auto rdB = [&](auto sc, auto jc) {
+      constexpr int s = decltype(sc)::value, j = decltype(jc)::value;
+      bz[s % RS][j] = ds_read64<(4 * s * LDZ + 4 * j) * 8>(COL ? aZc : aZr);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<0, RS>([&](auto sc) { rdA(sc); static_for<0, NQ>([&](auto jc) { rdB(sc, jc); }); });
+    static_for<0, 16>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      static_for<0, NQ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        // reads requested behind B(s, j): the rest of step s, the steps s + 1 .. s + RS - 1, and what M(s, 0 .. j - 1) re-requested
+        constexpr int last = (s + RS - 1) < 15 ? (s + RS - 1) : 15;
+        constexpr int newer = (NQ - 1 - j) + (last - s) * (NQ + 1) + ((s + RS <= 15 && j >= 1) ? j + 1 : 0);
+        static_assert(newer <= 15, "lgkmcnt is a 4-bit counter");
+        lgkm_wait<newer>();
+        if constexpr (s == 0) mfma444_zero(tq[j], ta[s % (RS + 1)], bz[s % RS][j]);
+        else mfma444_acc(tq[j], ta[s % (RS + 1)], bz[s % RS][j]);
+        if constexpr (s + RS <= 15) {
+          if constexpr (j == 0) rdA(IC<s + RS>{});
+          rdB(IC<s + RS>{}, jc);
+        }
+      });
+      if constexpr (NQ < 3) asm volatile("s_nop 15");                     // dependent accumulation: the asm MFMAs get no automatic wait states
+    });
+    mfma_drain(tq[NQ - 1]);
+    acc_fence<NQ>(tq);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // fold one side's t into its grad_Z accumulator; returns r (broadcast inside the lane quad) and leaves p[qq] = z t if wanted.  The four
+  // table reads per q-quad are asm reads one quad ahead (left to the compiler all 4 NQ loads are hoisted: 100 VGPRs in flight)
+  auto fold = [&](const double (&tq)[NQ], double (&G)[NQ], unsigned aZo, unsigned aQt, double* p) -> double {
+    const double r = quad_xchg<0xFF>(tq[NQ - 1]);                         // the ones column sits at q = QT - 1 (qq = NQ - 1, li = 3)
+    double tb[2][4];
+    auto rdF = [&](auto qc, double (&t_)[4]) {
+      constexpr int qq = decltype(qc)::value;
+      t_[0] = ds_read64<(4 * qq) * 8>(aZo); t_[1] = ds_read64<(4 * qq) * 8>(aQt);
+      t_[2] = ds_read64<(QT + 4 * qq) * 8>(aQt); t_[3] = ds_read64<(2 * QT + 4 * qq) * 8>(aQt);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    rdF(IC<0>{}, tb[0]);
+    static_for<0, NQ>([&](auto qc) {
+      constexpr int qq = decltype(qc)::value, cur = qq & 1;
+      if constexpr (qq + 1 < NQ) { rdF(IC<qq + 1>{}, tb[cur ^ 1]); lgkm_wait<4>(); }
+      else lgkm_wait<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      const double z = tb[cur][0], kap = tb[cur][1], c1 = tb[cur][2], c2 = tb[cur][3];
+      G[qq] = fma(tq[qq], kap, fma(r, fma(-z, c1, c2), G[qq]));
+      if (p) p[qq] = z * tq[qq];
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    return r;
+  };
+  // ---- the next point's Q-vectors travel while the current point computes (LEA is requested at the start of phase A: GEMM1 covers it)
+  double nq0 = 0.0, nq1 = 0.0, nq2 = 0.0;
   auto load_point = [&](long n) {
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) nlr[rb] = a.LEA[n * a.Mp + 64 * I + 16 * rb + 4 * lb + lk];
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) nlc[cq] = a.LEA[n * a.Mp + 64 * J + 16 * w + 4 * cq + li];
     if (ts < a.Q) {
       const double wq = a.WP[n * a.QB + ts];
-      nq0 = a.V2P[n * a.QB + ts]; nq1 = a.alphaP[ts] + wq; nq2 = 2.0 * wq * a.MUP[n * a.QB + ts];
+      nq0 = 2.0 * a.V2P[n * a.QB + ts]; nq1 = a.alphaP[ts] + wq; nq2 = 2.0 * wq * a.MUP[n * a.QB + ts];     // kappa = alpha - w = 2 (-2 V)
     }
   };
-  long n = na + g;
-  bool act = n < nb;
-  if (act) load_point(n);
-  long n_prev = -1;
-  const int iters = (int)((nb - na + 1) / 2);
+  // Schedule: the two streams run half a point apart.  Stream g is in phase A (GEMM1, exp, tile store) of its point i at half-step
+  // 2 i + g and in phase B (both contractions, folds, sums) at 2 i + g + 1; every half-step starts with one workgroup barrier, so a
+  // SIMD always hosts one wave in each phase.
+  const long cnt_g = (nb > na) ? (nb - na + 1 - g) / 2 : 0;                 // points of this stream: na + g, na + g + 2, ...
+  const int H = (nb > na) ? (int)(nb - na) + 2 : 0;                         // half-steps 0 .. H - 1 cover both streams' last phase B and its flush
+  if (cnt_g > 0) load_point(na + g);
+  long n_flush = -1;
   __syncthreads();
-  for (int it = 0; it < iters; ++it) {
-    double* qt = qtb + (g * 2 + (it & 1)) * (3 * QT);
-    if (act && ts < QT) { qt[ts] = ts < a.Q ? nq0 : 0.0; qt[QT + ts] = ts < a.Q ? nq1 : 0.0; qt[2 * QT + ts] = ts < a.Q ? nq2 : 0.0; }
-    double lrow[4], lcol[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { lrow[k] = nlr[k]; lcol[k] = nlc[k]; }
-    const long n_cur = n;
-    const bool act_cur = act;
-    n += 2;
-    act = n < nb;
-    if (act) load_point(n);
-    __syncthreads();                                                                   // barrier A
-    if (n_prev >= 0 && ts < PW) {
-      // the previous point's sums of this stream: four waves -> pp[tile][i][n]   (i = 0: s0 = the ones column of s1)
+  for (int h = 0; h < H; ++h) {
+    const int hh = h - g;
+    const bool isA = (hh & 1) == 0;
+    const long i = hh >> 1;
+    const bool act = hh >= 0 && i < cnt_g;
+    double* qt = qtb + (g * 2 + (int)(i & 1)) * (3 * QT);
+    const long n_cur = na + g + 2 * i;
+    if (isA && act) {
+      if (ts < QT) { qt[ts] = ts < a.Q ? nq0 : 0.0; qt[QT + ts] = ts < a.Q ? nq1 : 0.0; qt[2 * QT + ts] = ts < a.Q ? nq2 : 0.0; }
+      if (i + 1 < cnt_g) load_point(n_cur + 2);
+    }
+    __syncthreads();
+    if (n_flush >= 0 && ts < PW) {
+      // the sums of this stream's previous phase B: four waves -> pp[tile][i][n]   (i = 0: s0 = the ones column of s1)
       const double* rp = redb + g * 4 * RW;
       const int src = ts == 0 ? QT - 1 : ((ts - 1) / a.Q) * QT + (ts - 1) % a.Q;
-      a.pp[((long)blockIdx.x * PW + ts) * a.CH + (n_prev - a.n0)] = (rp[src] + rp[RW + src]) + (rp[2 * RW + src] + rp[3 * RW + src]);
+      a.pp[((long)blockIdx.x * PW + ts) * a.CH + (n_flush - a.n0)] = (rp[src] + rp[RW + src]) + (rp[2 * RW + src] + rp[3 * RW + src]);
     }
-    double S1 = 0.0, S2 = 0.0, S3 = 0.0;
-    if (act_cur) {
+    n_flush = -1;
+    if (!act) continue;
+    if (isA) {
       // ---- GEMM1 (operands of step k4 + 1 are read while the 16 MFMAs of step k4 execute; counted waits: only asm LDS reads in here)
       double T[4][4];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) T[rb][cq] = 0.0;
-      // the zeros become asm-defined values HERE: left to the register allocator they are rematerialised (v_mov 0) right in front of the
-      // first asm MFMA of each accumulator -- a VALU write the MFMA reads without wait states, on a register the previous MFMA may still read
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc_fence<4>(T[rb]);
       {
         const unsigned aV = lds_byte_addr(qt) + 8u * (unsigned)lk;
         double av[2][4], bv[2][4], vv[2];
@@ -179,141 +255,88 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int cq = 0; cq < 4; ++cq) mfma444_acc(T[rb][cq], av[cur][rb], bv[cur][cq]);
+            for (int cq = 0; cq < 4; ++cq) {
+              if constexpr (k4 == 0) mfma444_zero(T[rb][cq], av[cur][rb], bv[cur][cq]);
+              else mfma444_acc(T[rb][cq], av[cur][rb], bv[cur][cq]);
+            }
         });
         mfma_drain(T[3][3]);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc_fence<4>(T[rb]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- T = Bbar o exp(E + LEA[n, row] + LEA[n, col])
+      // ---- T = Bbar o exp(E + LEA[n, row] + LEA[n, col]),  E = 1/2 sum_q kappa_q z_mq z_m'q;  tile -> LDS.  The 24 per-lane operands are
+      // requested only now (held through GEMM1 they cost 48 VGPRs at the kernel's register peak); the SIMD's other wave is in phase B meanwhile
+      double lrow[4], lcol[4], bb[4][4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) lrow[rb] = a.LEA[n_cur * a.Mp + 64 * I + 16 * rb + 4 * lb + lk];
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) lcol[cq] = a.LEA[n_cur * a.Mp + 64 * J + 16 * w + 4 * cq + li];
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq) T[rb][cq] = bb[rb][cq] * fexp(T[rb][cq] + lrow[rb] + lcol[cq]);
-      if (offd) {
-        // T^T into LDS for the row side: element (row, col) at tx[col][row]
+        for (int cq = 0; cq < 4; ++cq) bb[rb][cq] = bbp[(long)(16 * rb) * a.Mp + 4 * cq];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+      for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
-          for (int cq = 0; cq < 4; ++cq) tx[(16 * w + 4 * cq + li) * TS + 16 * rb + 4 * lb + lk] = T[rb][cq];
-      }
-      // ---- column side: t[col][q] over the tile's 64 rows, four q-quads at a time; de-replicated into tq[qq] (col 16 w + 4 lb + lk, q = 4 qq + li)
-      double tq[NQ];
-      static_for<0, NG>([&](auto gc) {
-        constexpr int gi = decltype(gc)::value, nq = NQ / NG + (gi < NQ % NG ? 1 : 0), qq0 = gi * (NQ / NG) + (gi < NQ % NG ? gi : NQ % NG);
-        double tc[4][nq];
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq)
-#pragma unroll
-          for (int j = 0; j < nq; ++j) tc[cq][j] = 0.0;
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) acc_fence<nq>(tc[cq]);             // asm-defined zeros (see GEMM1)
-        double b2[2][nq];
-        auto rd2 = [&](auto rc, double (&b_)[nq]) {
-          constexpr int rb = decltype(rc)::value;
-          static_for<0, nq>([&](auto jc) { constexpr int j = decltype(jc)::value; b_[j] = ds_read64<(16 * rb * LDZ + 4 * (qq0 + j)) * 8>(aB2); });
-        };
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        rd2(IC<0>{}, b2[0]);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc_fence<4>(T[rb]);
-        asm volatile("s_nop 4");                                          // VALU-written T -> MFMA operand
-        static_for<0, 4>([&](auto rc) {
-          constexpr int rb = decltype(rc)::value, cur = rb & 1;
-          if constexpr (rb + 1 < 4) { rd2(IC<rb + 1>{}, b2[cur ^ 1]); lgkm_wait<nq>(); }
-          else lgkm_wait<0>();
-#pragma unroll
-          for (int cq = 0; cq < 4; ++cq)
-#pragma unroll
-            for (int j = 0; j < nq; ++j) mfma444_acc(tc[cq][j], T[rb][cq], b2[cur][j]);
-        });
-        mfma_drain(tc[3][nq - 1]);
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) acc_fence<nq>(tc[cq]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < nq; ++j) {
-          const double four[4] = {tc[0][j], tc[1][j], tc[2][j], tc[3][j]};
-          double two[2], one[1];
-          halve<4, 2>(four, two, lane);
-          halve<2, 3>(two, one, lane);
-          tq[qq0 + j] = one[0];
+        for (int cq = 0; cq < 4; ++cq) {
+          const double t = bb[rb][cq] * fexp(fma(0.5, T[rb][cq], lrow[rb]) + lcol[cq]);
+          tx[wb + cq * (4 * TXS) + 16 * rb + ((rb & 1) ? -pofs : pofs)] = t;
         }
-      });
+        __builtin_amdgcn_sched_barrier(0);       // four exponentials at a time: all sixteen interleaved cost ~100 VGPRs of temporaries
+      }
+    } else {
+      // ---- column side: t[col][q] over the 64 rows of the tile -> grad_Z of slab J's rows, s3 (z^T T z of the mirrored tile is the same number)
+      double tq[NQ], p[NQ];
+      contract(IC<1>{}, tq);
+      const unsigned aQt = lds_byte_addr(qt) + 8u * (unsigned)li;
+      const double rc = fold(tq, Gc, lds_byte_addr(zj) + 8u * (unsigned)((16 * w + 4 * lb + lk) * LDZ + li), aQt, p);
+      double S3 = reduce16<NQ>(p, lane);
+      if (offd) S3 *= 2.0;
+      // pin the results HERE (asm statements keep their order): otherwise the whole fold is sunk below the row side's contraction -- its
+      // basic block -- and 4 NQ table values + NQ sums stay live across it (the register peak of the kernel)
+      acc_fence<NQ>(Gc);
+      asm volatile("" : "+v"(S3));
+      if (li == 3) rr[4 * lb + lk] = rc;
+      if (offd) {
+        // ---- row side: t[row][q] over the 64 columns -> grad_Z of slab I's rows
+        contract(IC<0>{}, tq);
+        const double rw_ = fold(tq, Gr, lds_byte_addr(zr) + 8u * (unsigned)((16 * w + 4 * lb + lk) * LDZ + li), aQt, nullptr);
+        acc_fence<NQ>(Gr);
+        if (li == 3) rr[16 + 4 * lb + lk] = rw_;
+      }
+      // ---- s1_q = sum z r, s2_q = sum z^2 r over the wave's 16 columns (and 16 rows): lane q, r broadcast from LDS
+      double S1 = 0.0, S2 = 0.0;
       {
-        // fold: this lane owns column mc = 16 w + 4 lb + lk of slab J and q = 4 qq + li
-        const double r = quad_xchg<0xFF>(tq[NQ - 1]);                     // the ones column sits at q = QT - 1 (qq = NQ - 1, li = 3)
-        const double* zo = zj + (16 * w + 4 * lb + lk) * LDZ + li;
-        double s1p[NQ], s2p[NQ], s3p[NQ];
-#pragma unroll
-        for (int qq = 0; qq < NQ; ++qq) {
-          const double z = zo[4 * qq], kap = 2.0 * qt[4 * qq + li], c1 = qt[QT + 4 * qq + li], c2 = qt[2 * QT + 4 * qq + li];
-          Gc[qq] = fma(tq[qq], kap, fma(r, fma(-z, c1, c2), Gc[qq]));
-          const double zr_ = z * r;
-          s1p[qq] = zr_; s2p[qq] = z * zr_; s3p[qq] = z * tq[qq];
-        }
-        S1 = reduce16<NQ>(s1p, lane); S2 = reduce16<NQ>(s2p, lane); S3 = reduce16<NQ>(s3p, lane);
-        if (offd) S3 *= 2.0;                                              // z^T T z of the mirrored tile is the same number
-      }
-    }
-    __syncthreads();                                                                   // barrier B: the T tiles are visible
-    if (act_cur) {
-      if (offd) {
-        // ---- row side: this wave owns rows 16 w .. 16 w + 15 of slab I across all 64 columns; result (row 16 w + 4 lb + lk, q = 4 qq + li)
-        double tq[NQ];
-        static_for<0, NG>([&](auto gc) {
-          // q-quads in NG groups of equal size (13 -> 4, 3, 3, 3): an accumulator is reused every nq MFMAs
-          constexpr int gi = decltype(gc)::value, nq = NQ / NG + (gi < NQ % NG ? 1 : 0), qq0 = gi * (NQ / NG) + (gi < NQ % NG ? gi : NQ % NG);
-          double tr[nq];
-#pragma unroll
-          for (int j = 0; j < nq; ++j) tr[j] = 0.0;
-          acc_fence<nq>(tr);                                              // asm-defined zeros (see GEMM1)
-          double ta[2], bz[2][nq];
-          auto rd3 = [&](auto cc, double& a_, double (&b_)[nq]) {
-            constexpr int c4 = decltype(cc)::value;
-            a_ = ds_read64<(4 * c4 * TS) * 8>(aT);
-            static_for<0, nq>([&](auto jc) { constexpr int j = decltype(jc)::value; b_[j] = ds_read64<(4 * c4 * LDZ + 4 * (qq0 + j)) * 8>(aZ); });
+        // every lane runs the loop (lanes >= QT read inside the arrays and drop the result): asm reads four entries ahead
+        const int lq = lane < QT ? lane : 0;
+        const unsigned aRr = lds_byte_addr(rr);
+        auto sums = [&](unsigned aZs, auto sidec) {
+          constexpr int side = decltype(sidec)::value;
+          double zb[4], rb_[4];
+          auto rdS = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            zb[c & 3] = ds_read64<(c * LDZ) * 8>(aZs); rb_[c & 3] = ds_read64<(16 * side + c) * 8>(aRr);
           };
           __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          rd3(IC<0>{}, ta[0], bz[0]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the wave's own r stores have landed
+          static_for<0, 3>([&](auto cc) { rdS(cc); });
           static_for<0, 16>([&](auto cc) {
-            constexpr int c4 = decltype(cc)::value, cur = c4 & 1;
-            if constexpr (c4 + 1 < 16) { rd3(IC<c4 + 1>{}, ta[cur ^ 1], bz[cur ^ 1]); lgkm_wait<nq + 1>(); }
-            else lgkm_wait<0>();
-#pragma unroll
-            for (int j = 0; j < nq; ++j) mfma444_acc(tr[j], ta[cur], bz[cur][j]);
-            if constexpr (nq < 3) asm volatile("s_nop 15");               // dependent accumulation: the asm MFMAs get no automatic wait states
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c + 3 < 16) { rdS(IC<c + 3>{}); lgkm_wait<6>(); }
+            else lgkm_wait<2 * (15 - c)>();
+            __builtin_amdgcn_sched_barrier(0);
+            const double zr_ = zb[c & 3] * rb_[c & 3];
+            S1 += zr_; S2 = fma(zb[c & 3], zr_, S2);
+            __builtin_amdgcn_sched_barrier(0);
           });
-          mfma_drain(tr[nq - 1]);
-          acc_fence<nq>(tr);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < nq; ++j) tq[qq0 + j] = tr[j];
-        });
-        const double r = quad_xchg<0xFF>(tq[NQ - 1]);
-        const double* zo = zr + (16 * w + 4 * lb + lk) * LDZ + li;
-        double s1p[NQ], s2p[NQ];
-#pragma unroll
-        for (int qq = 0; qq < NQ; ++qq) {
-          const double z = zo[4 * qq], kap = 2.0 * qt[4 * qq + li], c1 = qt[QT + 4 * qq + li], c2 = qt[2 * QT + 4 * qq + li];
-          Gr[qq] = fma(tq[qq], kap, fma(r, fma(-z, c1, c2), Gr[qq]));
-          const double zr_ = z * r;
-          s1p[qq] = zr_; s2p[qq] = z * zr_;
-        }
-        S1 += reduce16<NQ>(s1p, lane); S2 += reduce16<NQ>(s2p, lane);
+        };
+        sums(lds_byte_addr(zj) + 8u * (unsigned)(16 * w * LDZ + lq), IC<0>{});
+        if (offd) sums(lds_byte_addr(zr) + 8u * (unsigned)(16 * w * LDZ + lq), IC<1>{});
+        if (lane < QT) { red[lane] = S1; red[QT + lane] = S2; red[2 * QT + lane] = S3; }
       }
-      if (lane < QT) { red[lane] = S1; red[QT + lane] = S2; red[2 * QT + lane] = S3; }
+      n_flush = n_cur;
     }
-    n_prev = act_cur ? n_cur : -1;
-  }
-  __syncthreads();
-  if (n_prev >= 0 && ts < PW) {
-    const double* rp = redb + g * 4 * RW;
-    const int src = ts == 0 ? QT - 1 : ((ts - 1) / a.Q) * QT + (ts - 1) % a.Q;
-    a.pp[((long)blockIdx.x * PW + ts) * a.CH + (n_prev - a.n0)] = (rp[src] + rp[RW + src]) + (rp[2 * RW + src] + rp[3 * RW + src]);
   }
   __syncthreads();
   // ---- grad_Z partials of the workgroup: the two streams are added through LDS (the tile buffers are free now)
@@ -396,7 +419,7 @@ __global__ void __launch_bounds__(256) pt2_gz_reduce_kernel(const double* __rest
 int pt2_width(int Q) { return Q <= 3 ? 4 : Q <= 7 ? 8 : Q <= 11 ? 12 : Q <= 15 ? 16 : Q <= 23 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : 0; }
 
 template <int QT>
-static size_t pt2_lds_bytes() { return ((size_t)2 * 64 * (QT + 2) + 2 * 64 * 65 + 2 * 2 * 3 * QT + 2 * 4 * 3 * QT) * sizeof(double); }
+static size_t pt2_lds_bytes() { return ((size_t)2 * 64 * (QT + 2) + 2 * 64 * TXS + 2 * 2 * 3 * QT + 2 * 4 * 3 * QT + 8 * 32) * sizeof(double); }
 
 template <int QT>
 static int launch_tile(gp_ctx* c, const PT2Args& a) {

@@ -153,6 +153,7 @@ struct gp_ctx {
   int* tiles64 = nullptr;     // upper-triangular 64x64 tile table for the MFMA pair kernel (wide latent spaces) and the tile-pair phase 2
   int n_tiles64 = 0;
   // regime-B phase 2 on tile pairs (psi2_tile.hip, Q <= 51)
+  bool b_tile = false;        // regime-B phase 2 runs on psi2_tile_kernel
   double* ppt = nullptr;      // [tiles][3Q+1][b_ch] per-point sums of every tile for the points of one launch
   double* Gt = nullptr;       // [b_S][tiles][2][64][Q] grad_Z partials per workgroup
   long b_ch = 0;              // points per launch
@@ -186,7 +187,7 @@ int run_phase1_b(gp_ctx* c);
 int run_phase2_b(gp_ctx* c);
 int run_dz2(gp_ctx* c);
 // psi2_tile.hip (regime B phase 2 on tile pairs)
-bool pt2_applicable(const gp_ctx* c);
+bool pt2_applicable(const gp_ctx* c, bool sym_available);
 int run_phase2_b_tiles(gp_ctx* c);
 // compat.hip
 int compat_build(gp_ctx* c, int which, double** out, long* count);

@@ -812,8 +812,6 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   c->ppb = (int)std::max<long>(16, (c->N + 4095) / 4096);
   c->pb_blocks = (int)((c->N + c->ppb - 1) / c->ppb);
   A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q); A(&c->Gtmp, (size_t)64 * M * Q);
-  // the tile-pair phase 2 (psi2_tile.hip) keeps its own per-launch buffer instead
-  A(&c->pp, pt2_applicable(c) ? 1 : (size_t)Np * (3 * c->QB + 1) * (c->b_mfma ? c->nslab : (c->nslab + 3) / 4));
   std::vector<int> t;
   const int Mt = (int)((M + 15) / 16);
   for (int i = 0; i < Mt; ++i) for (int j = i; j < Mt; ++j) { t.push_back(i); t.push_back(j); }
@@ -834,6 +832,10 @@ int ensure_regime_b_buffers(gp_ctx* c) {
     const size_t smem = ((size_t)Mp * RTs + (size_t)nw * (3 * c->QB + 1)) * sizeof(double);
     c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
   }
+  // the matrix-core tile-pair phase 2 (psi2_tile.hip) wherever psi2_sym_kernel does not apply; it keeps its own per-launch sums buffer
+  c->b_tile = pt2_applicable(c, c->b_sym);
+  if (c->b_tile) c->b_sym = false;
+  A(&c->pp, c->b_tile ? 1 : (size_t)Np * (3 * c->QB + 1) * (c->b_mfma ? c->nslab : (c->nslab + 3) / 4));
   std::vector<int> sch;
   if (c->b_sym) {
     const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2;
@@ -987,7 +989,7 @@ static int launch_cols_mfma(gp_ctx* c, const PB2Args& a) {
 
 int run_phase2_b(gp_ctx* c) {
   if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
-  if (pt2_applicable(c)) return run_phase2_b_tiles(c);
+  if (c->b_tile) return run_phase2_b_tiles(c);
   PB2Args a;
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;

@@ -429,10 +429,16 @@ static int launch_tile(gp_ctx* c, const PT2Args& a) {
   return GP_OK;
 }
 
-// the tile-pair phase 2 applies when a compiled width has room for the column of ones (Q <= 51); GPARML_B_PHASE2=cols keeps the older kernels
-bool pt2_applicable(const gp_ctx* c) {
-  static const bool off = [] { const char* e = getenv("GPARML_B_PHASE2"); return e && std::string(e) == "cols"; }();
-  return !off && pt2_width(c->Q) > 0;
+// The tile-pair phase 2 applies when a compiled width has room for the column of ones (Q <= 51) and is used from Q = 17 on: the per-point
+// folds and sums do not shrink with Q, so below that the VALU kernels of psi2.hip are faster (same-box, ms of the phase-2 kernel per 1e5
+// points: Q = 4, M = 512: 21.7 (cols) vs 41.8 here; Q = 10, M = 512: 31.7 (psi2_sym) vs 40.5; Q = 16, M = 512: 47.2 vs 56.5;
+// Q = 20, M = 256: 23.1 vs 17.0; Q = 24, M = 512: 93.9 vs 69.7; Q = 50, M = 1024, 2e4 points: 96.4 (psi2_cols_mfma) vs 75.8).
+// GPARML_B_PHASE2=cols keeps the older kernels everywhere, =tiles forces this one.  Decided once per context (c->b_tile).
+bool pt2_applicable(const gp_ctx* c, bool sym_available) {
+  static const int mode = [] { const char* e = getenv("GPARML_B_PHASE2"); return !e ? 0 : (std::string(e) == "cols" ? 1 : (std::string(e) == "tiles" ? 2 : 0)); }();
+  (void)sym_available;
+  if (mode == 1 || pt2_width(c->Q) == 0) return false;
+  return mode == 2 || c->Q >= 17;
 }
 
 int run_phase2_b_tiles(gp_ctx* c) {

@@ -55,8 +55,28 @@ def _psi2_terms_chunk(Z, s2, a, mu, S):
     return psi2, w, d2
 
 
+def _psi2_terms_chunk_gemm(Z, s2, a, mu, S):
+    """The same (n, M, M) tensor as _psi2_terms_chunk with the coupling term as a batched GEMM instead of a contraction with the
+    (M, M, Q) table of squared differences: -1/4 sum_q v_q (z_mq - z_m'q)^2 = -1/4 (v.z_m^2) - 1/4 (v.z_m'^2) + 1/2 sum_q v_q z_mq z_m'q.
+    Ten times faster at M = 1024, Q = 50 (the table is 400 MB there); used by the large-shape GPU tests (``pairs='gemm'``), pinned
+    against the direct form by tests/test_oracle_factorised.py."""
+    d2 = 2.0 * a[None, :] * S + 1.0
+    w = a[None, :] / d2
+    c2 = s2 * s2 / np.sqrt(np.prod(d2, axis=1))
+    lnE = -0.5 * (np.sum(w * mu * mu, axis=1)[:, None] - 2.0 * (w * mu).dot(Z.T) + w.dot((Z * Z).T))   # (n, M)
+    v = a[None, :] - w                                                                                 # (n, Q) >= 0
+    A = lnE - 0.25 * v.dot((Z * Z).T)                                                                  # (n, M)
+    G = np.matmul(Z[None, :, :] * v[:, None, :], Z.T)                                                  # (n, M, M) = Z diag(v_n) Z^T
+    G *= 0.5
+    G += A[:, :, None]
+    G += A[:, None, :]
+    np.exp(G, out=G)
+    G *= c2[:, None, None]
+    return G, w, d2
+
+
 # ----------------------------------------------------------------------------------------- phase 1
-def phase1(Z, sf2, alpha, Y, X_mu, X_S, chunk=4096):
+def phase1(Z, sf2, alpha, Y, X_mu, X_S, chunk=4096, pairs='direct'):
     """Per-shard sufficient statistics.  [partial_terms.py:38-52, 74-87; kernel_exp.py:13-148]"""
     Z, s2, a, _ = _as_params(Z, sf2, alpha, 1.0)
     N_s, D = Y.shape
@@ -77,7 +97,7 @@ def phase1(Z, sf2, alpha, Y, X_mu, X_S, chunk=4096):
         if regA:
             Psi2 += P1.T.dot(P1)
         else:
-            psi2, _, _ = _psi2_terms_chunk(Z, s2, a, mu, S)
+            psi2, _, _ = (_psi2_terms_chunk_gemm if pairs == 'gemm' else _psi2_terms_chunk)(Z, s2, a, mu, S)
             Psi2 += psi2.sum(0)
             KL += 0.5 * float(np.sum(np.sum(S - np.log(S), 1) + np.sum(mu * mu, 1) - Q))
     return dict(sum_exp_K_mi_K_im=Psi2, exp_K_miY=C, sum_YYT=sum_YYT, sum_exp_K_ii=s2 * N_s, KL=KL if not regA else 0.0)
@@ -156,7 +176,7 @@ def global_step(Z, sf2, alpha, beta, stats, N_global, D, fixed_beta=False, linal
 
 
 # ----------------------------------------------------------------------------------------- phase 2
-def phase2(Z, sf2, alpha, Y, X_mu, X_S, Abar, Bbar, chunk=4096, want_embeddings=True):
+def phase2(Z, sf2, alpha, Y, X_mu, X_S, Abar, Bbar, chunk=4096, want_embeddings=True, pairs='direct'):
     """Data-dependent parts of grad_Z / grad_alpha (to be summed over shards) and the local
     grad_X_mu / grad_X_S.  The alpha term -1/4 sum (Bbar o Psi2)(z-z')^2 that needs only the reduced
     Psi2 is added by ``finish`` (it is not a per-shard sum).
@@ -192,7 +212,7 @@ def phase2(Z, sf2, alpha, Y, X_mu, X_S, Abar, Bbar, chunk=4096, want_embeddings=
             if not regA:
                 gS[lo:hi] = -0.5 * (1.0 - 1.0 / S) + 0.5 * u * u * quad1 - 0.5 * u * h[:, None]
         if not regA:
-            psi2, w, d2 = _psi2_terms_chunk(Z, s2, a, mu, S)
+            psi2, w, d2 = (_psi2_terms_chunk_gemm if pairs == 'gemm' else _psi2_terms_chunk)(Z, s2, a, mu, S)
             T = psi2 * Bbar[None, :, :]
             r = T.sum(2)                                      # (n, M)
             t = T.dot(Z)                                      # (n, M, Q): sum_m' T[m,m'] z_m'q
@@ -222,13 +242,14 @@ def finish(Z, sf2, alpha, gstep, p2_sum, regime_A):
     return dict(F=gstep['F'], grad_Z=gZ, grad_alpha=ga, grad_sf2=gstep['grad_sf2'], grad_beta=gstep['grad_beta'])
 
 
-def evaluate(Z, sf2, alpha, beta, Y, X_mu, X_S, N_global=None, chunk=4096, want_embeddings=True, fixed_beta=False):
-    """One evaluation on a single shard (the sequence phase1 -> global_step -> phase2 -> finish)."""
+def evaluate(Z, sf2, alpha, beta, Y, X_mu, X_S, N_global=None, chunk=4096, want_embeddings=True, fixed_beta=False, pairs='direct'):
+    """One evaluation on a single shard (the sequence phase1 -> global_step -> phase2 -> finish).  ``pairs='gemm'``: the per-point psi2
+    tensor through a batched GEMM (_psi2_terms_chunk_gemm) -- for the shapes where the direct form takes minutes."""
     N_s, D = Y.shape
     Ng = N_s if N_global is None else N_global
-    st = phase1(Z, sf2, alpha, Y, X_mu, X_S, chunk)
+    st = phase1(Z, sf2, alpha, Y, X_mu, X_S, chunk, pairs=pairs)
     gs = global_step(Z, sf2, alpha, beta, st, Ng, D, fixed_beta)
-    p2 = phase2(Z, sf2, alpha, Y, X_mu, X_S, gs['Abar'], gs['Bbar'], chunk, want_embeddings)
+    p2 = phase2(Z, sf2, alpha, Y, X_mu, X_S, gs['Abar'], gs['Bbar'], chunk, want_embeddings, pairs=pairs)
     out = finish(Z, sf2, alpha, gs, p2, is_regime_A(X_S))
     out['grad_X_mu'], out['grad_X_S'] = p2['grad_X_mu'], p2['grad_X_S']
     out['stats'], out['gstep'] = st, gs
@@ -252,31 +273,68 @@ def synthetic_shard(N, D, M, Q, regime='A', seed=0, zseed=1, alpha_value=None):
     return dict(Y=Y, X_mu=X_mu, X_S=X_S, Z=Z, sf2=1.0, alpha=np.full(Q, float(alpha_value)), beta=10.0)
 
 
+# ----------------------------------------------------------------------------------------- shards in threads
+def evaluate_sharded(Z, sf2, alpha, beta, Y, X_mu, X_S, shards=8, workers=None, want_embeddings=True, pairs='direct', chunk=4096):
+    """The same evaluation as ``evaluate`` with the points cut into ``shards`` contiguous shards whose phase 1 / phase 2 run in a thread
+    pool (numpy releases the GIL in its large kernels) and are summed in shard order -- exactly the map/reduce the path is built on
+    (local_MapReduce.py:115-171, 250-277).  For the large-shape GPU tests, where one thread needs minutes."""
+    from multiprocessing.pool import ThreadPool
+    N_s, D = Y.shape
+    cuts = [int(round(i * N_s / float(shards))) for i in range(shards + 1)]
+    parts = [(cuts[i], cuts[i + 1]) for i in range(shards) if cuts[i + 1] > cuts[i]]
+    pool = ThreadPool(workers or len(parts))
+    try:
+        sts = pool.map(lambda ab: phase1(Z, sf2, alpha, Y[ab[0]:ab[1]], X_mu[ab[0]:ab[1]], X_S[ab[0]:ab[1]], chunk, pairs=pairs), parts)
+        st = dict(sts[0])
+        for o in sts[1:]:
+            for k in ('sum_exp_K_mi_K_im', 'exp_K_miY', 'sum_YYT', 'sum_exp_K_ii', 'KL'):
+                st[k] = st[k] + o[k]
+        gs = global_step(Z, sf2, alpha, beta, st, N_s, D)
+        p2s = pool.map(lambda ab: phase2(Z, sf2, alpha, Y[ab[0]:ab[1]], X_mu[ab[0]:ab[1]], X_S[ab[0]:ab[1]], gs['Abar'], gs['Bbar'], chunk,
+                                         want_embeddings, pairs=pairs), parts)
+    finally:
+        pool.close()
+    p2 = dict(grad_Z_data=sum(o['grad_Z_data'] for o in p2s), grad_alpha_data=sum(o['grad_alpha_data'] for o in p2s))
+    out = finish(Z, sf2, alpha, gs, p2, is_regime_A(X_S))
+    out['grad_X_mu'] = np.concatenate([o['grad_X_mu'] for o in p2s]) if p2s[0]['grad_X_mu'] is not None else None
+    out['grad_X_S'] = np.concatenate([o['grad_X_S'] for o in p2s]) if p2s[0]['grad_X_S'] is not None else None
+    out['stats'], out['gstep'] = st, gs
+    return out
+
+
 # ----------------------------------------------------------------------------------------- BLAS-bound CPU baseline
-def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixed_beta=False, work=None, linalg='cholesky'):
+def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixed_beta=False, work=None, linalg='cholesky', workers=1):
     """Regime A with fixed embeddings (X_S == 0, no per-point gradients) arranged so that the time goes into DGEMM: the same
     formulation as phase1 / global_step / phase2 / finish above, but K_nm is generated once per chunk and KEPT for phase 2 (the
     two-phase protocol regenerates it), the two back-propagation products are GEMMs on K and Y into one buffer, element-wise work is
     done in place in buffers that are reused from chunk to chunk (``work``: pass the same dict again to reuse them across calls),
     and grad_alpha's mu^2 term uses the row sums of W.  This is what bench.py times as the CPU baseline (kind "port"): large chunks,
-    all BLAS threads.  Checked against evaluate() by tests/test_oracle_factorised.py."""
+    all BLAS threads.  ``workers`` > 1 runs the chunks of each phase in a thread pool (the element-wise numpy work -- exp, products, row
+    sums over 32768 x 512 arrays -- is single-threaded per call, numpy releases the GIL) and adds the partial sums in chunk order; the
+    caller divides the BLAS threads among the workers.  Checked against evaluate() by tests/test_oracle_factorised.py."""
     Z, s2, a, b = _as_params(Z, sf2, alpha, beta)
     N_s, D = Y.shape
     M, Q = Z.shape
     Ng = N_s if N_global is None else N_global
     work = {} if work is None else work
     nch = (N_s + chunk - 1) // chunk
-    if work.get('shape') != (N_s, M, chunk):
+    workers = max(1, min(int(workers), nch))
+    if work.get('shape') != (N_s, M, chunk, workers):
         work.clear()
-        work['shape'] = (N_s, M, chunk)
+        work['shape'] = (N_s, M, chunk, workers)
         work['K'] = [np.empty((min(chunk, N_s - i * chunk), M)) for i in range(nch)]
-        work['W'] = np.empty((min(chunk, N_s), M))
+        work['W'] = [np.empty((min(chunk, N_s), M)) for _ in range(workers)]
     Z2a = (Z * Z).dot(a)                                        # sum_q a_q z_mq^2
     Za = (Z * a[None, :]).T.copy()                              # (Q, M)
-    Psi2 = np.zeros((M, M))
-    C = np.zeros((M, D))
-    sum_YYT = 0.0
-    for i in range(nch):
+    if workers > 1:
+        from multiprocessing.pool import ThreadPool
+        pool = ThreadPool(workers)
+        run = lambda f: pool.map(f, range(nch))
+    else:
+        pool = None
+        run = lambda f: [f(i) for i in range(nch)]
+
+    def p1(i):
         lo, hi = i * chunk, min(N_s, (i + 1) * chunk)
         mu, Yc, E = X_mu[lo:hi], Y[lo:hi], work['K'][i]
         np.dot(mu, Za, out=E)                                   # (n, M)
@@ -287,26 +345,42 @@ def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixe
         np.exp(E, out=E)
         if s2 != 1.0:
             E *= s2
-        Psi2 += E.T.dot(E)
-        C += E.T.dot(Yc)
-        sum_YYT += float(np.einsum('ij,ij->', Yc, Yc))
-    st = dict(sum_exp_K_mi_K_im=Psi2, exp_K_miY=C, sum_YYT=sum_YYT, sum_exp_K_ii=s2 * N_s, KL=0.0)
-    gs = global_step(Z, sf2, alpha, beta, st, Ng, D, fixed_beta, linalg=linalg)
-    B2 = np.ascontiguousarray(2.0 * gs['Bbar'].T)              # G[n, j] = sum_m' K[n, m'] 2 Bbar[j, m'] (partial_terms.py:238)
-    At = np.ascontiguousarray(gs['Abar'].T)                     # G = K (2 Bbar) + Y Abar^T
+        return E.T.dot(E), E.T.dot(Yc), float(np.einsum('ij,ij->', Yc, Yc))
+
+    try:
+        parts = run(p1)
+        Psi2 = np.zeros((M, M))
+        C = np.zeros((M, D))
+        sum_YYT = 0.0
+        for P_, C_, s_ in parts:                                # chunk order: the result does not depend on the worker count
+            Psi2 += P_
+            C += C_
+            sum_YYT += s_
+        st = dict(sum_exp_K_mi_K_im=Psi2, exp_K_miY=C, sum_YYT=sum_YYT, sum_exp_K_ii=s2 * N_s, KL=0.0)
+        gs = global_step(Z, sf2, alpha, beta, st, Ng, D, fixed_beta, linalg=linalg)
+        B2 = np.ascontiguousarray(2.0 * gs['Bbar'].T)              # G[n, j] = sum_m' K[n, m'] 2 Bbar[j, m'] (partial_terms.py:238)
+        At = np.ascontiguousarray(gs['Abar'].T)                     # G = K (2 Bbar) + Y Abar^T
+
+        def p2(i):
+            lo, hi = i * chunk, min(N_s, (i + 1) * chunk)
+            K, mu, Yc = work['K'][i], X_mu[lo:hi], Y[lo:hi]
+            W = work['W'][i % workers][:hi - lo] if workers == 1 else np.empty((hi - lo, M))
+            np.dot(K, B2, out=W)
+            W += Yc.dot(At)
+            W *= K                                                  # W = G o K
+            return W.T.dot(mu), W.sum(0), W.sum(1).dot(mu * mu)
+
+        parts = run(p2)
+    finally:
+        if pool is not None:
+            pool.close()
     R1 = np.zeros((M, Q))
     R0 = np.zeros(M)
     hmu2 = np.zeros(Q)
-    for i in range(nch):
-        lo, hi = i * chunk, min(N_s, (i + 1) * chunk)
-        K, mu, Yc = work['K'][i], X_mu[lo:hi], Y[lo:hi]
-        W = work['W'][:hi - lo]
-        np.dot(K, B2, out=W)
-        W += Yc.dot(At)
-        W *= K                                                  # W = G o K
-        R1 += W.T.dot(mu)
-        R0 += W.sum(0)
-        hmu2 += W.sum(1).dot(mu * mu)
+    for r1, r0, h2 in parts:
+        R1 += r1
+        R0 += r0
+        hmu2 += h2
     gZ = a[None, :] * (R1 - Z * R0[:, None])
     ga = -0.5 * (hmu2 - 2.0 * np.sum(Z * R1, axis=0) + (Z * Z).T.dot(R0))
     out = finish(Z, sf2, alpha, gs, dict(grad_Z_data=gZ, grad_alpha_data=ga), True)

@@ -1,0 +1,71 @@
+"""Regime-B phase 2 on tile pairs (gparml_amd/csrc/psi2_tile.hip; reference: partial_terms.py:190-205, 273-284, 388-394, 421-427).
+
+The kernel is in charge from Q = 17 on (below that the VALU kernels of psi2.hip are faster), so the seeded shapes of test_gpu_parity.py
+reach it only at its three widest instantiations.  Here: (1) every compiled width (4 ... 52), several point chunks per launch, diagonal-only
+and many-tile layouts, with the kernel forced (GPARML_B_PHASE2=tiles, read once per process: a child process); (2) BASELINE configs[4]'s
+per-GPU shape (D=1000, M=1024, Q=50) with MORE points than inducing points (N=2048, alpha = 1/Q), against the oracle evaluated in
+sixteen shards on the host's threads."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_close
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+# N, D, M, Q, alpha: widths 4, 8, 12, 16, 24, 32, 52; one slab .. five slabs (15 tiles); 9000 and 20000 points = 2 and 3 launches of 8192
+SHAPES = [(300, 5, 20, 3, 0.5), (9000, 3, 200, 6, 0.3), (1000, 7, 130, 10, 0.3), (20000, 2, 64, 11, 0.2), (640, 3, 33, 13, 0.2), (500, 4, 300, 15, 0.1),
+          (400, 2, 70, 20, 0.1), (700, 2, 129, 23, 0.1), (300, 2, 40, 30, 0.08), (350, 2, 65, 31, 0.05), (200, 2, 24, 50, 0.05), (257, 2, 1, 1, 1.0),
+          (333, 2, 100, 51, 0.03)]
+for (N, D, M, Q, alpha) in SHAPES:
+    d = Fz.synthetic_shard(N, D, M, Q, regime='B', seed=31, zseed=32, alpha_value=alpha)
+    ref = Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=8, pairs='gemm')
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    out = eng.evaluate(True)
+    eng.close()
+    assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F']), (N, D, M, Q)
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S'):
+        err = np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))
+        assert err <= 1e-5, ((N, D, M, Q), k, err)
+    print('TILE_OK', N, D, M, Q)
+'''
+
+
+def test_every_compiled_width_with_the_kernel_forced(tmp_path):
+    script = tmp_path / 'tile_child.py'
+    script.write_text(CHILD % {'root': ROOT})
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1800, cwd=ROOT, env=dict(os.environ, GPARML_B_PHASE2='tiles'))
+    assert r.returncode == 0 and r.stdout.count('TILE_OK') == 13, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_config4_shape_with_more_points_than_inducing_points():
+    """D=1000, M=1024, Q=50, free embeddings, N=2048 > M, alpha = 1/Q (the regime BASELINE configs[4] runs in: A = K_mm + beta Psi2 is
+    dominated by the statistics, not a low-rank update of K_mm as in test_gpu_parity.test_config4_shape): 136 tiles, two point streams,
+    the column-of-ones and padding columns of the 52-wide instantiation."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import factorised as Fz
+    N, D, M, Q = 2048, 1000, 1024, 50
+    rs = np.random.RandomState(7)
+    d = Fz.synthetic_shard(N, D, 64, Q, regime='B', seed=6, zseed=7, alpha_value=1.0 / Q)
+    d['Z'] = d['X_mu'][rs.permutation(N)[:M]] + 0.3 * rs.randn(M, Q)
+    ref = Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=32, workers=min(32, os.cpu_count() or 8),
+                              pairs='gemm')
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    out = eng.evaluate(True)
+    eng.close()
+    assert_close(out['F'], ref['F'], 1e-6, what='F')
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S'):
+        assert_close(out[k], ref[k], 1e-5, what=k)

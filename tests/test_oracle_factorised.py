@@ -101,3 +101,31 @@ def test_blas_bound_baseline_equals_the_two_phase_port():
         assert abs(out['F'] - ref['F']) <= 1e-11 * abs(ref['F'])
         for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'):
             assert np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) <= 1e-8 * np.max(np.abs(ref[k])), k
+
+
+def test_threaded_and_lu_variants_of_the_baseline():
+    """evaluate_blas with its chunks in a thread pool adds the partial sums in chunk order: bit-identical to the serial call; with
+    linalg='lu' (the reference's LU arrangement of the global step, oracle/literal.py) it is the same evaluation to rounding."""
+    from oracle import factorised as Fz
+    d = Fz.synthetic_shard(6000, 5, 48, 4, regime='A', seed=5, zseed=6, alpha_value=0.5)
+    a = Fz.evaluate_blas(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], chunk=1000)
+    b = Fz.evaluate_blas(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], chunk=1000, workers=3)
+    c = Fz.evaluate_blas(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], chunk=1000, linalg='lu')
+    assert a['F'] == b['F'] and np.array_equal(a['grad_Z'], b['grad_Z']) and np.array_equal(a['grad_alpha'], b['grad_alpha'])
+    assert abs(c['F'] - a['F']) <= 1e-11 * abs(a['F'])
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'):
+        assert np.max(np.abs(np.asarray(c[k]) - np.asarray(a[k]))) <= 1e-8 * np.max(np.abs(a[k])), k
+
+
+def test_gemm_pair_tensor_and_sharded_evaluation_equal_the_direct_form():
+    """The two accelerations the large-shape GPU tests use -- the per-point psi2 tensor through a batched GEMM (pairs='gemm') and the
+    shards-in-threads evaluation -- are the same evaluation as evaluate() (both regimes)."""
+    from oracle import factorised as Fz
+    for regime in ('A', 'B'):
+        d = Fz.synthetic_shard(700, 5, 40, 7, regime=regime, seed=1, zseed=2, alpha_value=0.3)
+        ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+        for out in (Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], pairs='gemm'),
+                    Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=5, pairs='gemm')):
+            assert abs(out['F'] - ref['F']) <= 1e-12 * abs(ref['F'])
+            for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu') + (('grad_X_S',) if regime == 'B' else ()):
+                assert np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) <= 1e-9 * np.max(np.abs(ref[k])), (regime, k)

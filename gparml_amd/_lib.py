@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgparml_hip.so')
+# GPARML_LIB: another build of the same library (tools/ab_bench.sh runs variants side by side without touching the in-tree one)
+LIB_PATH = os.environ.get('GPARML_LIB') or os.path.join(_HERE, 'libgparml_hip.so')
 
 GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_ERR_HIP, GP_ERR_STATE, GP_ERR_UNSUPPORTED, GP_RETRY_JITTER = range(8)
 
@@ -33,6 +34,9 @@ SIGNATURES = {
     'gp_set_globals': (ctypes.c_int, [_vp, _dp, ctypes.c_double, _dp, ctypes.c_double, _i64, ctypes.c_double]),
     'gp_phase1': (ctypes.c_int, [_vp]),
     'gp_stats_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    'gp_stats_packed_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
+    'gp_stats_pack': (ctypes.c_int, [_vp]),
+    'gp_stats_unpack': (ctypes.c_int, [_vp]),
     'gp_scale_stats': (ctypes.c_int, [_vp, ctypes.c_double]),
     'gp_scale_buffer': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
     'gp_debug_force_staging': (ctypes.c_int, [ctypes.c_int]),
@@ -107,4 +111,8 @@ def raise_for(rc, lib, ctx, what):
         raise np.linalg.LinAlgError(msg)
     if rc == GP_ERR_NON_FINITE:
         raise FloatingPointError(msg)
+    if rc == GP_RETRY_JITTER:
+        # a factorisation failed and the caller of this entry point cannot repeat the global step (the evaluators catch JitterRetry
+        # before this): the class the optimiser's failure wrapper handles (scg_adapted.py:55)
+        raise np.linalg.LinAlgError(msg)
     raise GparmlHipError(msg)

@@ -167,7 +167,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
                     c->HZp, c->gXmu, c->gXs, c->gapart, c->hgpart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
-                    c->Gpart, c->Gtmp, c->gapart2, c->pp, c->Z1S, c->ppt, c->Gt};
+                    c->Gpart, c->Gtmp, c->gapart2, c->pp, c->Z1S, c->ppt, c->Gt, c->spack};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);
   if (c->ptiles) (void)hipFree(c->ptiles);
@@ -310,6 +310,58 @@ extern "C" int gp_stats_buffer(gp_ctx* c, void** dev_ptr, int64_t* n) {
   return GP_OK;
 }
 
+// ---- packed statistics for the all-reduce across processes: Psi2 upper triangle (row-major) | C [M][D] | scalars
+__global__ void __launch_bounds__(256) stats_pack_kernel(const double* __restrict__ stats, double* __restrict__ pk, int M, int Mp, int D, int Dp, int unpack_) {
+  const long tri = (long)M * (M + 1) / 2, md = (long)M * D;
+  double* st = const_cast<double*>(stats);
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)M * M + md + SC_COUNT; e += (long)gridDim.x * 256L) {
+    if (e < (long)M * M) {
+      const int i = (int)(e / M), j = (int)(e - (long)i * M);
+      if (j < i) continue;
+      const long k = (long)i * M - (long)i * (i - 1) / 2 + (j - i);
+      if (unpack_) { const double v = pk[k]; st[(long)i * Mp + j] = v; st[(long)j * Mp + i] = v; }
+      else pk[k] = stats[(long)i * Mp + j];
+    } else if (e < (long)M * M + md) {
+      const long r = e - (long)M * M;
+      const int i = (int)(r / D), d = (int)(r - (long)i * D);
+      if (unpack_) st[(long)Mp * Mp + (long)i * Dp + d] = pk[tri + r];
+      else pk[tri + r] = stats[(long)Mp * Mp + (long)i * Dp + d];
+    } else {
+      const long r = e - (long)M * M - md;
+      if (unpack_) st[(long)Mp * Mp + (long)Mp * Dp + r] = pk[tri + md + r];
+      else pk[tri + md + r] = stats[(long)Mp * Mp + (long)Mp * Dp + r];
+    }
+  }
+}
+static int64_t spack_doubles(const gp_ctx* c) { return (int64_t)c->M * (c->M + 1) / 2 + (int64_t)c->M * c->D + SC_COUNT; }
+static int ensure_spack(gp_ctx* c) {
+  if (!c->spack) {
+    GP_HIP(c, hipMalloc((void**)&c->spack, (size_t)spack_doubles(c) * sizeof(double)));
+    GP_HIP(c, hipMemsetAsync(c->spack, 0, (size_t)spack_doubles(c) * sizeof(double), c->stream));
+  }
+  return GP_OK;
+}
+extern "C" int gp_stats_packed_buffer(gp_ctx* c, void** dev_ptr, int64_t* n) {
+  if (!c) return GP_ERR_BAD_ARG;
+  GP_HIP(c, hipSetDevice(c->device));
+  GP_TRY(ensure_spack(c));
+  if (dev_ptr) *dev_ptr = c->spack;
+  if (n) *n = spack_doubles(c);
+  return GP_OK;
+}
+static int stats_pack(gp_ctx* c, int unpack_) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (c->state < 1) return fail(c, GP_ERR_STATE, "gp_stats_pack / gp_stats_unpack before gp_phase1");
+  GP_HIP(c, hipSetDevice(c->device));
+  GP_TRY(ensure_spack(c));
+  const long n = (long)c->M * c->M + (long)c->M * c->D + SC_COUNT;
+  hipLaunchKernelGGL(stats_pack_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, (const double*)c->stats, c->spack, c->M, c->Mp, c->D, c->Dp, unpack_);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+extern "C" int gp_stats_pack(gp_ctx* c) { return stats_pack(c, 0); }
+extern "C" int gp_stats_unpack(gp_ctx* c) { return stats_pack(c, 1); }
+
 extern "C" int gp_grads_buffer(gp_ctx* c, void** dev_ptr, int64_t* n) {
   if (!c) return GP_ERR_BAD_ARG;
   if (dev_ptr) *dev_ptr = c->grads;
@@ -374,6 +426,12 @@ extern "C" int gp_scale_buffer(gp_ctx* c, int which, double f) {
   if (which == 1 && c->state < 3) return fail(c, GP_ERR_STATE, "gp_scale_buffer(gradient sums) before gp_phase2");
   GP_HIP(c, hipSetDevice(c->device));
   const long n = which == 0 ? (long)c->Mp * c->Mp + (long)c->Mp * c->Dp + SC_COUNT : (long)c->M * c->Q + c->Q;
+  if (f == 0.0) {
+    // a dropped shard: the reference never loads its files (local_MapReduce.py:119-129) -- a memset, so that non-finite values in
+    // the dropped shard's sums (0 * inf = nan) cannot reach the reduction
+    GP_HIP(c, hipMemsetAsync(which == 0 ? c->stats : c->grads, 0, (size_t)n * sizeof(double), c->stream));
+    return GP_OK;
+  }
   hipLaunchKernelGGL(scale_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, which == 0 ? c->stats : c->grads, n, f);
   GP_HIP(c, hipGetLastError());
   return GP_OK;

@@ -77,6 +77,7 @@ struct gp_ctx {
   double* Zaug = nullptr;     // [Mp][CZp]
   double* stats = nullptr;    // packed: Psi2 [Mp*Mp] | C [Mp*Dp] | scalars [SC_COUNT]
   bool stats_external = false;
+  double* spack = nullptr;    // Psi2 upper triangle | C [M][D] | scalars: the all-reduce payload across processes (allocated on first use)
   double* grads = nullptr;    // packed: gZ_data [M*Q] | galpha_data [Q]
   bool grads_external = false;
   double* staging = nullptr;  // landing buffer for a peer copy from a shard on another device (gp_buffer_combine)
@@ -194,6 +195,9 @@ int compat_build(gp_ctx* c, int which, double** out, long* count);
 // linalg.hip
 int run_global_step(gp_ctx* c);
 int check_global(gp_ctx* c);
+// PRECONDITION: the 128-blocks of Linv strictly above the block diagonal must be ZERO on entry -- they are never written here and
+// Inv = Linv^T Linv reads the whole matrix.  gp_create allocates Linv zeroed and nothing else writes those blocks; the test hook
+// gp_debug_potrf_inverse memsets its own buffer.  A caller that hands in a reused scratch buffer must clear it first.
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,
                           double* Twork /*[batch][128][Mp]*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/,
                           double* splitk_ws /*may be NULL*/);

@@ -39,6 +39,7 @@ class DistributedEvaluator(object):
         self._grads_t = None
         self.device = device
         self.force = force_collectives and dist.is_initialized()
+        self._packed = False
         self.time_collectives = False     # bench.py: device-side time of the two all-reduces of the last evaluation
         self._cev = None
 
@@ -49,7 +50,9 @@ class DistributedEvaluator(object):
                 s, g = self.engine.host_buffers()
                 self._stats_t, self._grads_t = torch.from_numpy(s), torch.from_numpy(g)
             else:
-                p, n = self.engine.stats_buffer()
+                # the packed form (Psi2's upper triangle, no padding) where the engine has it: 1.46 MB instead of 2.6 MB at M=512, D=100
+                self._packed = hasattr(self.engine, 'stats_packed_buffer')
+                p, n = self.engine.stats_packed_buffer() if self._packed else self.engine.stats_buffer()
                 self._stats_t = device_tensor(p, n, self.device)
                 p, n = self.engine.grads_buffer()
                 self._grads_t = device_tensor(p, n, self.device)
@@ -79,11 +82,15 @@ class DistributedEvaluator(object):
         if not kept_here:
             eng.scale_buffer('stats', 0.0)
         if collective:
+            if self._packed:
+                eng.stats_pack()
             if cev:
                 cev[0].record()
             self.dist.all_reduce(stats_t, op=self.dist.ReduceOp.SUM, group=self.group)
             if cev:
                 cev[1].record()
+            if self._packed:
+                eng.stats_unpack()
         if rescale:
             eng.scale_buffer('stats', 1.0 / kept_fraction)
         jitter = 0

@@ -85,6 +85,18 @@ class ShardEngine(object):
     def phase1(self):
         self._ck(self.lib.gp_phase1(self.h), 'gp_phase1')
 
+    def stats_packed_buffer(self):
+        """Psi2 upper triangle | C (M*D) | scalars: the payload of the all-reduce across processes (stats_pack / stats_unpack)."""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._ck(self.lib.gp_stats_packed_buffer(self.h, ctypes.byref(p), ctypes.byref(n)), 'gp_stats_packed_buffer')
+        return p.value, n.value
+
+    def stats_pack(self):
+        self._ck(self.lib.gp_stats_pack(self.h), 'gp_stats_pack')
+
+    def stats_unpack(self):
+        self._ck(self.lib.gp_stats_unpack(self.h), 'gp_stats_unpack')
+
     def stats_buffer(self):
         p, n = ctypes.c_void_p(), ctypes.c_int64()
         self._ck(self.lib.gp_stats_buffer(self.h, ctypes.byref(p), ctypes.byref(n)), 'gp_stats_buffer')
@@ -133,11 +145,13 @@ class ShardEngine(object):
         ``sync=False`` (the evaluators) defers all of that to finish(), the evaluation's single host synchronisation."""
         self._ck(self.lib.gp_global_step_jitter(self.h, int(jitter)), 'gp_global_step')
         if sync:
-            try:
-                self.global_status()
-            except _lib.JitterRetry as r:
-                self._ck(self.lib.gp_global_step_jitter(self.h, r.mask), 'gp_global_step')
-                self.global_status()
+            for _ in range(2):                  # at most one retry per matrix: the mask only grows (Kmm, then Kmm + beta Psi2)
+                try:
+                    self.global_status()
+                    return
+                except _lib.JitterRetry as r:
+                    self._ck(self.lib.gp_global_step_jitter(self.h, r.mask), 'gp_global_step')
+            self.global_status()                # a third failure is GP_ERR_NOT_PD -> LinAlgError
 
     def global_status(self):
         mask = ctypes.c_int(0)
@@ -165,14 +179,15 @@ class ShardEngine(object):
     def evaluate(self, want_embedding_grads=False):
         """Single-shard evaluation (no reduction across shards); one host synchronisation, in finish()."""
         self.phase1()
-        self.global_step(sync=False)
-        self.phase2(want_embedding_grads)
-        try:
-            out = self.finish()
-        except _lib.JitterRetry as r:
-            self.global_step(sync=False, jitter=r.mask)
+        jitter = 0
+        while True:                             # the retry mask only grows (bit 0 Kmm, bit 1 Kmm + beta Psi2): at most two repeats
+            self.global_step(sync=False, jitter=jitter)
             self.phase2(want_embedding_grads)
-            out = self.finish()
+            try:
+                out = self.finish()
+                break
+            except _lib.JitterRetry as r:
+                jitter = r.mask
         if want_embedding_grads:
             out['grad_X_mu'] = self.download('GRAD_X_MU')
             if not self.regime_A_hint:

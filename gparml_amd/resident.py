@@ -63,9 +63,16 @@ class ResidentModel(object):
         from .dist import device_tensor
         import torch
         root = self.engines[0]
-        p, n = root.stats_buffer() if which == 'stats' else root.grads_buffer()
+        if which == 'stats':
+            # across processes the statistics travel without padding and without Psi2's lower triangle (gp_stats_pack / gp_stats_unpack)
+            root.stats_pack()
+            p, n = root.stats_packed_buffer()
+        else:
+            p, n = root.grads_buffer()
         t = device_tensor(p, n, torch.device('cuda', root.device))
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        if which == 'stats':
+            root.stats_unpack()
         self.n_collectives += 1
 
     def close(self):

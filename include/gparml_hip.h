@@ -15,7 +15,7 @@
  *     precision -- the argument meaning of partial_terms.__init__ (partial_terms.py:16-36).
  *
  * One evaluation (parallel_GPLVM.py:222-279) is
- *   gp_set_globals -> gp_phase1 -> [all-reduce gp_stats_buffer] -> gp_global_step
+ *   gp_set_globals -> gp_phase1 -> [gp_stats_pack, all-reduce gp_stats_packed_buffer, gp_stats_unpack] -> gp_global_step
  *                  -> gp_phase2 -> [all-reduce gp_grads_buffer] -> gp_finish
  */
 #ifndef GPARML_HIP_H
@@ -99,6 +99,13 @@ int gp_phase1(gp_ctx* ctx);
 /* packed device buffer the host all-reduces (sum) across shards: the statistics_reducer
  * (local_MapReduce.py:250-277).  Layout: Psi2 (Mp*Mp) | C (Mp*Dp) | sum_YYT, Psi0, KL, n_local, pad(4) */
 int gp_stats_buffer(gp_ctx* ctx, void** dev_ptr, int64_t* n_doubles);
+/* The same statistics without padding and without the lower triangle, for the all-reduce across processes (what the reducer's twelve
+ * accumulated_statistics files carry, local_MapReduce.py:250-277): Psi2 upper triangle, row-major (M(M+1)/2) | C (M*D) | the 8 scalars.
+ * gp_stats_pack(ctx) fills it from the statistics buffer (after gp_phase1 and any drop-out scaling), gp_stats_unpack(ctx) writes the
+ * reduced values back (both triangles) before gp_global_step.  1.46 MB instead of 2.6 MB at M=512, D=100. */
+int gp_stats_packed_buffer(gp_ctx* ctx, void** dev_ptr, int64_t* n_doubles);
+int gp_stats_pack(gp_ctx* ctx);
+int gp_stats_unpack(gp_ctx* ctx);
 /* device-side reduce for several shards in one process (statistics_reducer, local_MapReduce.py:250-277), on one GPU or
  * across GPUs (peer copy into a staging buffer of dst): which=0 statistics buffer, which=1 phase-2 gradient-sum buffer;
  * op=0 dst += src, op=1 dst = src */

@@ -138,3 +138,102 @@ def test_two_rank_resident_optimisation_reproduces_the_reference_runs(tmp_path):
            '--master-port', str(port), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0 and r.stdout.count('RANK_OK') == 2, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+EIGHT_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from gparml_amd.engine import ShardEngine
+from gparml_amd.dist import DistributedEvaluator, draw_kept_mask
+from gparml_amd.resident import ResidentCG, ResidentModel
+from oracle import factorised as Fz
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+N, D, M, Q = 2400, 5, 48, 5
+cut = [int(round(i * N / float(world))) + (7 if 0 < i < world else 0) for i in range(world + 1)]      # ragged shards
+a, b = cut[rank], cut[rank + 1]
+for regime in ('A', 'B'):
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=41, zseed=42, alpha_value=0.5)
+    eng = ShardEngine(b - a, D, M, Q)
+    eng.upload_shard(d['Y'][a:b], d['X_mu'][a:b], d['X_S'][a:b])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
+    ev = DistributedEvaluator(eng, device=torch.device('cuda', 0))
+    out = ev.evaluate(regime == 'B')
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])
+    assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F']), (out['F'], ref['F'])
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'):
+        assert np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) <= 1e-5 * np.max(np.abs(ref[k])), k
+    # node drop-out at world_size 8: every rank draws the same mask from the shared seed; the kept shards alone, rescaled, are the oracle's
+    # statistics of the kept rows divided by the kept fraction (local_MapReduce.py:119-129, 263-264)
+    kept, frac = draw_kept_mask(world, 0.4, np.random.RandomState(5))
+    assert 0 < sum(kept) < world
+    out = ev.evaluate(False, kept_mask=kept, kept_fraction=frac)
+    rows = np.concatenate([np.arange(cut[r], cut[r + 1]) for r in range(world) if kept[r]])
+    st = Fz.phase1(d['Z'], d['sf2'], d['alpha'], d['Y'][rows], d['X_mu'][rows], d['X_S'][rows])
+    for k in ('sum_exp_K_mi_K_im', 'exp_K_miY', 'sum_YYT', 'sum_exp_K_ii', 'KL'):
+        st[k] = st[k] / frac
+    gs = Fz.global_step(d['Z'], d['sf2'], d['alpha'], d['beta'], st, N, D)
+    assert abs(out['F'] - gs['F']) <= 1e-6 * abs(gs['F']), ('drop-out', out['F'], gs['F'])
+    eng.close()
+# the jitter branch taken by all eight ranks together: statistics that make Kmm + beta Psi2 barely indefinite on every rank
+d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=43, zseed=44, alpha_value=0.5)
+from oracle import literal as L
+Kmm = L.rbf_gram(d['Z'], d['sf2'], d['alpha'])
+lam = np.linalg.eigvalsh(Kmm)[0]
+class Fixed(ShardEngine):
+    def phase1(self):
+        ShardEngine.phase1(self)
+        # every rank contributes 1/world of a Psi2 that shifts the smallest eigenvalue of Kmm + beta Psi2 to -5e-8
+        self.set_local_statistics(1.0, -(lam + 5e-8) / d['beta'] * np.eye(M) / world, np.zeros((M, D)), d['sf2'] * (b - a), 0.0)
+eng = Fixed(b - a, D, M, Q)
+eng.upload_shard(d['Y'][a:b], d['X_mu'][a:b], d['X_S'][a:b])
+eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
+out = DistributedEvaluator(eng, device=torch.device('cuda', 0)).evaluate(False)
+assert np.isfinite(out['F']) and np.all(np.isfinite(out['grad_Z']))
+Fs = [None] * world
+dist.all_gather_object(Fs, out['F'])
+assert len(set(Fs)) == 1, Fs                      # the replicated global step (with the retry) gives the same bits on every rank
+eng.close()
+# resident SCG helpers at world_size 8: the reductions over eight shards equal the single-process values
+d = Fz.synthetic_shard(N, D, M, Q, regime='B', seed=45, zseed=46, alpha_value=0.5)
+raw = np.log(np.exp(d['X_S']) - 1.0)
+model = ResidentModel([(d['Y'][a:b], d['X_mu'][a:b], raw[a:b])], M, Q, D, fixed_embeddings=False)
+assert model.N == N
+x = np.concatenate([d['Z'].ravel(), [0.5], np.full(Q, 0.3), [1.2]])
+f, g = model.likelihood_and_gradient(x, 0)
+cg = ResidentCG(model)
+cg.embeddings_set_grads(None)
+vals = np.array([cg.embeddings_get_grads_mu(), cg.embeddings_get_grads_kappa(), cg.embeddings_get_grads_current_grad()])
+alls = [None] * world
+dist.all_gather_object(alls, (f, vals))
+assert all(abs(o[0] - alls[0][0]) == 0 and np.array_equal(o[1], alls[0][1]) for o in alls)
+model.close()
+dist.destroy_process_group()
+print('RANK_OK', rank)
+"""
+
+
+def test_eight_ranks_on_one_device(tmp_path):
+    """world_size 8 (BASELINE configs[3] / [4] run at 8 ranks) on a 1-GPU box: eight processes share device 0 over gloo.  Covers what
+    depends on the rank count: ragged eight-way sharding against the oracle (both regimes), the shared-seed drop-out mask with several
+    dropped ranks, the jitter retry taken by all ranks together, the resident optimiser reductions, and bench.py --gpus 8 end to end
+    with its all-reduce timings."""
+    script = tmp_path / 'eight_rank_script.py'
+    script.write_text(EIGHT_RANK_SCRIPT % {'root': ROOT})
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and r.stdout.count('RANK_OK') == 8, r.stdout[-2000:] + r.stderr[-6000:]
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GPARML_BENCH_ONE_DEVICE='1', GPARML_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1',
+           '--N', '20000', '--D', '12', '--M', '96', '--Q', '5']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert res['n_gpus'] == 8 and res['scaling'] == 'weak' and res['value'] > 0
+    assert res['config']['allreduce_ms']['total'] > 0 and res['config']['global_ms'] > 0 and 'cpu_baseline' not in res and 'extra' not in res

@@ -4,8 +4,7 @@ set -u
 cd "$(dirname "$0")/.."
 for r in 1 2; do
   for v in "$@"; do
-    cp gparml_amd/lib_$v.so.bin gparml_amd/libgparml_hip.so
-    python3 bench.py --steps 3 --warmup 1 --regime B --no-cpu-baseline | python3 -c "
+    GPARML_LIB=$PWD/gparml_amd/lib_$v.so.bin python3 bench.py --steps 3 --warmup 1 --regime B --no-cpu-baseline | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'], 2), 'F', d['config']['F'])"
   done

@@ -847,9 +847,18 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
       const int I = wave * 2 + i;
       const int row = swap03(I * 8 + (ld_ >> 3));
       // byte offset as an unsigned 32-bit value: uniform base + 32-bit lane offset addressing (one address register instead of two)
+#if !defined(GPARML_ABLATE_P2_DMA) || GPARML_ABLATE_P2_DMA < 2
       glds16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(a) + (unsigned)(8 * (row * (int)p.ld + 2 * ((ld_ & 7) ^ (row & 7))))),
              buf + I * 8 * KC);
+#endif
+      // ablation builds (tools/r03_p2_ablate.sh; wrong results, same instruction stream otherwise): 1 = the B tile is staged for every
+      // second chunk only -- 25 % fewer LDS-DMA instructions per flop, what a 256 x 128 workgroup tile would issue; 2 = no staging at all
+#if defined(GPARML_ABLATE_P2_DMA) && GPARML_ABLATE_P2_DMA == 1
+      if ((reinterpret_cast<size_t>(b) / (KC * 8 * (size_t)p.Mp)) & 1)
+#endif
+#if !defined(GPARML_ABLATE_P2_DMA) || GPARML_ABLATE_P2_DMA < 2
       glds16(b + (long)I * p.Mp + 2u * ld_, buf + TILE_LDS_DOUBLES + I * LDS_RC);
+#endif
     }
   };
   // Epilogue addressing is derived from an OPAQUE copy of the lane id at its point of use: as loop invariants these values

@@ -22,6 +22,7 @@
 #include "quad_mma.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace gp {
 
@@ -32,6 +33,7 @@ struct PT2Args {
   double* pp;           // [T][3Q+1][CH] per-point sums of every tile for the points of this launch
   long n0, n1, CH, Np;
   int Mp, M, Q, QB, T, S, accumulate;
+  long long* dbg;       // timing build (GPARML_TILE_TIMING): [blocks][8 waves][8 sections] cycle totals
 };
 
 template <int MASK>
@@ -100,6 +102,12 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
   const long per = (a.n1 - a.n0 + a.S - 1) / a.S;
   const long na = a.n0 + (long)blockIdx.y * per, nb = min(a.n1, na + per);
   const int PW = 3 * a.Q + 1;
+#ifdef GPARML_TILE_TIMING
+  long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define TSEC(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); tsec[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define TSEC(k)
+#endif
   for (int e = tid; e < 64 * QT; e += 512) {
     const int r = e / QT, q = e - r * QT;
     const double one = (q == QT - 1) ? 1.0 : 0.0;
@@ -157,13 +165,19 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
         constexpr int last = (s + RS - 1) < 15 ? (s + RS - 1) : 15;
         constexpr int newer = (NQ - 1 - j) + (last - s) * (NQ + 1) + ((s + RS <= 15 && j >= 1) ? j + 1 : 0);
         static_assert(newer <= 15, "lgkmcnt is a 4-bit counter");
+#ifndef GPARML_TILE_ABLATE_READS
         lgkm_wait<newer>();
+#else
+        if constexpr (s == 0 && j == 0) lgkm_wait<0>();
+#endif
         if constexpr (s == 0) mfma444_zero(tq[j], ta[s % (RS + 1)], bz[s % RS][j]);
         else mfma444_acc(tq[j], ta[s % (RS + 1)], bz[s % RS][j]);
+#ifndef GPARML_TILE_ABLATE_READS      /* ablation build: stale operands, no LDS reads in the contractions' main loop */
         if constexpr (s + RS <= 15) {
           if constexpr (j == 0) rdA(IC<s + RS>{});
           rdB(IC<s + RS>{}, jc);
         }
+#endif
       });
       if constexpr (NQ < 3) asm volatile("s_nop 15");                     // dependent accumulation: the asm MFMAs get no automatic wait states
     });
@@ -222,7 +236,9 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
       if (ts < QT) { qt[ts] = ts < a.Q ? nq0 : 0.0; qt[QT + ts] = ts < a.Q ? nq1 : 0.0; qt[2 * QT + ts] = ts < a.Q ? nq2 : 0.0; }
       if (i + 1 < cnt_g) load_point(n_cur + 2);
     }
+    TSEC(1)
     __syncthreads();
+    TSEC(0)
     if (n_flush >= 0 && ts < PW) {
       // the sums of this stream's previous phase B: four waves -> pp[tile][i][n]   (i = 0: s0 = the ones column of s1)
       const double* rp = redb + g * 4 * RW;
@@ -231,9 +247,25 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
     }
     n_flush = -1;
     if (!act) continue;
+#if defined(GPARML_TILE_ABLATE) && GPARML_TILE_ABLATE == 3          /* ablation: no phase A at all (stale tile) */
+    if (isA) continue;
+#endif
+#if defined(GPARML_TILE_ABLATE) && GPARML_TILE_ABLATE == 4          /* ablation: no phase B at all */
+    if (!isA) continue;
+#endif
     if (isA) {
       // ---- GEMM1 (operands of step k4 + 1 are read while the 16 MFMAs of step k4 execute; counted waits: only asm LDS reads in here)
       double T[4][4];
+      // the 24 per-lane operands of the exp stage are requested before GEMM1, which covers their latency (L2: ~1.5k cycles)
+      double lrow[4], lcol[4], bb[4][4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) lrow[rb] = a.LEA[n_cur * a.Mp + 64 * I + 16 * rb + 4 * lb + lk];
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) lcol[cq] = a.LEA[n_cur * a.Mp + 64 * J + 16 * w + 4 * cq + li];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) bb[rb][cq] = bbp[(long)(16 * rb) * a.Mp + 4 * cq];
       {
         const unsigned aV = lds_byte_addr(qt) + 8u * (unsigned)lk;
         double av[2][4], bv[2][4], vv[2];
@@ -265,30 +297,33 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
         for (int rb = 0; rb < 4; ++rb) acc_fence<4>(T[rb]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- T = Bbar o exp(E + LEA[n, row] + LEA[n, col]),  E = 1/2 sum_q kappa_q z_mq z_m'q;  tile -> LDS.  The 24 per-lane operands are
-      // requested only now (held through GEMM1 they cost 48 VGPRs at the kernel's register peak); the SIMD's other wave is in phase B meanwhile
-      double lrow[4], lcol[4], bb[4][4];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) lrow[rb] = a.LEA[n_cur * a.Mp + 64 * I + 16 * rb + 4 * lb + lk];
-#pragma unroll
-      for (int cq = 0; cq < 4; ++cq) lcol[cq] = a.LEA[n_cur * a.Mp + 64 * J + 16 * w + 4 * cq + li];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) bb[rb][cq] = bbp[(long)(16 * rb) * a.Mp + 4 * cq];
+      TSEC(2)
+      // ---- T = Bbar o exp(E + LEA[n, row] + LEA[n, col]),  E = 1/2 sum_q kappa_q z_mq z_m'q;  tile -> LDS
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
+#if defined(GPARML_TILE_ABLATE) && GPARML_TILE_ABLATE == 1      /* ablation: no exponential */
+          const double t = bb[rb][cq] * (fma(0.5, T[rb][cq], lrow[rb]) + lcol[cq]);
+#else
           const double t = bb[rb][cq] * fexp(fma(0.5, T[rb][cq], lrow[rb]) + lcol[cq]);
+#endif
           tx[wb + cq * (4 * TXS) + 16 * rb + ((rb & 1) ? -pofs : pofs)] = t;
         }
         __builtin_amdgcn_sched_barrier(0);       // four exponentials at a time: all sixteen interleaved cost ~100 VGPRs of temporaries
       }
+      TSEC(3)
     } else {
       // ---- column side: t[col][q] over the 64 rows of the tile -> grad_Z of slab J's rows, s3 (z^T T z of the mirrored tile is the same number)
       double tq[NQ], p[NQ];
       contract(IC<1>{}, tq);
+#if defined(GPARML_TILE_ABLATE) && GPARML_TILE_ABLATE == 2        /* ablation: contractions only (no folds, no sums) */
+      if (offd) contract(IC<0>{}, p);
+      Gc[0] += tq[0] + p[1];
+      n_flush = n_cur;
+      continue;
+#endif
+      TSEC(4)
       const unsigned aQt = lds_byte_addr(qt) + 8u * (unsigned)li;
       const double rc = fold(tq, Gc, lds_byte_addr(zj) + 8u * (unsigned)((16 * w + 4 * lb + lk) * LDZ + li), aQt, p);
       double S3 = reduce16<NQ>(p, lane);
@@ -298,6 +333,7 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
       acc_fence<NQ>(Gc);
       asm volatile("" : "+v"(S3));
       if (li == 3) rr[4 * lb + lk] = rc;
+      TSEC(5)
       if (offd) {
         // ---- row side: t[row][q] over the 64 columns -> grad_Z of slab I's rows
         contract(IC<0>{}, tq);
@@ -305,6 +341,7 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
         acc_fence<NQ>(Gr);
         if (li == 3) rr[16 + 4 * lb + lk] = rw_;
       }
+      TSEC(6)
       // ---- s1_q = sum z r, s2_q = sum z^2 r over the wave's 16 columns (and 16 rows): lane q, r broadcast from LDS
       double S1 = 0.0, S2 = 0.0;
       {
@@ -336,8 +373,12 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
         if (lane < QT) { red[lane] = S1; red[QT + lane] = S2; red[2 * QT + lane] = S3; }
       }
       n_flush = n_cur;
+      TSEC(7)
     }
   }
+#ifdef GPARML_TILE_TIMING
+  if (a.dbg && lane == 0) for (int k = 0; k < 8; ++k) a.dbg[((long)(blockIdx.y * a.T + blockIdx.x) * 8 + wave) * 8 + k] = tsec[k];
+#endif
   __syncthreads();
   // ---- grad_Z partials of the workgroup: the two streams are added through LDS (the tile buffers are free now)
   double* gs = smem;        // [2 streams][2 sides][64][QT]
@@ -462,6 +503,13 @@ int run_phase2_b_tiles(gp_ctx* c) {
   PT2Args a;
   a.ZP = c->ZP; a.Bbar = c->Bbar; a.LEA = c->LET; a.V2P = c->V2P; a.WP = c->WP; a.MUP = c->MUP; a.alphaP = c->alphaP;
   a.tiles = c->tiles64; a.Gt = c->Gt; a.pp = c->ppt; a.CH = c->b_ch; a.Np = c->Np; a.Mp = c->Mp; a.M = c->M; a.Q = Q; a.QB = c->QB; a.T = T; a.S = c->b_S;
+  a.dbg = nullptr;
+#ifdef GPARML_TILE_TIMING
+  static long long* dbg = nullptr;
+  const size_t ndbg = (size_t)c->b_S * T * 64;
+  if (!dbg) GP_HIP(c, hipMalloc((void**)&dbg, ndbg * sizeof(long long)));
+  a.dbg = dbg;
+#endif
   PT2Fin f;
   f.pp = c->ppt; f.Wn = c->Wn; f.mu = c->mu; f.S = c->S; f.alpha = c->alpha; f.gmu = c->gXmu; f.gS = c->gXs; f.gapart2 = c->gapart2; f.CH = c->b_ch; f.Q = Q;
   const int fin_blocks = (int)std::min<long>(c->pb_blocks, 256);
@@ -489,6 +537,20 @@ int run_phase2_b_tiles(gp_ctx* c) {
     GP_HIP(c, hipGetLastError());
   }
   (void)hipEventRecord(c->ev[13], c->stream);
+#ifdef GPARML_TILE_TIMING
+  {
+    std::vector<long long> h(ndbg);
+    GP_HIP(c, hipMemcpy(h.data(), dbg, ndbg * sizeof(long long), hipMemcpyDeviceToHost));
+    // an off-diagonal tile (the last one: I < J) of slice 0, waves 0 (stream 0) and 4 (stream 1); s_memtime ticks at 100 MHz
+    const long t = T - 1;
+    const char* names[8] = {"barrier", "prep", "GEMM1", "exp+store", "col contract", "col fold+s3", "row contract+fold", "s1/s2 sums"};
+    for (int wv : {0, 4}) {
+      fprintf(stderr, "[tile timing] last launch, tile %ld wave %d (ticks of s_memtime):", t, wv);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%lld", names[k], h[(size_t)(t * 8 + wv) * 8 + k]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   const long MQ = (long)c->M * Q;
   hipLaunchKernelGGL(pt2_gz_reduce_kernel, dim3((unsigned)std::min<long>((MQ + Q + 255) / 256, 2048)), dim3(256), 0, c->stream, (const double*)c->Gt,
                      (const int*)c->tiles64, T, c->b_S, c->M, Q, (const double*)c->gapart2, fin_blocks, c->grads);

@@ -541,8 +541,8 @@ int run_phase2_b_tiles(gp_ctx* c) {
   {
     std::vector<long long> h(ndbg);
     GP_HIP(c, hipMemcpy(h.data(), dbg, ndbg * sizeof(long long), hipMemcpyDeviceToHost));
-    // an off-diagonal tile (the last one: I < J) of slice 0, waves 0 (stream 0) and 4 (stream 1); s_memtime ticks at 100 MHz
-    const long t = T - 1;
+    // tile (0, 1) of slice 0, waves 0 (stream 0) and 4 (stream 1); s_memtime ticks at 100 MHz
+    const long t = 1;       // (0, 1): an off-diagonal tile
     const char* names[8] = {"barrier", "prep", "GEMM1", "exp+store", "col contract", "col fold+s3", "row contract+fold", "s1/s2 sums"};
     for (int wv : {0, 4}) {
       fprintf(stderr, "[tile timing] last launch, tile %ld wave %d (ticks of s_memtime):", t, wv);

@@ -253,6 +253,9 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
 #if defined(GPARML_TILE_ABLATE) && GPARML_TILE_ABLATE == 4          /* ablation: no phase B at all */
     if (!isA) continue;
 #endif
+    // the waves in phase B issue first: its contractions then run at the MFMA rate and its latency-bound tail (folds, reduce-scatter, sums)
+    // starts earlier, under the other stream's GEMM1 (same-box A/B, profiles/r03_tile_kernel_ab.txt: -2 % at Q = 50, -6 % at Q = 10; phase A first: +2 % / +6 %)
+    if (isA) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
     if (isA) {
       // ---- GEMM1 (operands of step k4 + 1 are read while the 16 MFMAs of step k4 execute; counted waits: only asm LDS reads in here)
       double T[4][4];

@@ -163,6 +163,9 @@ struct gp_ctx {
   double* g_latest = nullptr;
   double* g_new = nullptr;
   double* g_old = nullptr;
+  // global step: a second stream for the product chain that does not depend on the other one (created on first use), fork / join events
+  hipStream_t side = nullptr;
+  hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
   // timing
   hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double t_ms[5] = {0, 0, 0, 0, 0};

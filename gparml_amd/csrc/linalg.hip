@@ -7,6 +7,7 @@
 // and every trace unchanged.
 #include "gp_common.h"
 #include "potrf128.h"
+#include <algorithm>
 #include <cmath>
 
 namespace gp {
@@ -277,11 +278,20 @@ int run_global_step(gp_ctx* c) {
   if (rc != GP_OK) return rc;
   double* Ki = c->Inv;
   double* P = c->Inv + mm;
-  // E = P C ; PsiE = Psi2 E ; T1 = E E^T ; T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki
+  // E = P C ; PsiE = Psi2 E ; T1 = E E^T   and, independent of it,   T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki.
+  // Every launch here is a handful of 5-12 us products that leave most of the chip idle, so the second chain runs on a side stream (fork /
+  // join by events; the small-tile GEMM needs no shared workspace).  Larger problems (> 256 tiles: split-k through the shared workspace) stay serial.
+  const bool two = (long)(Mp / TILE) * (std::max(Mp, Dp) / TILE) <= 256;
+  if (two && !c->side) {
+    GP_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) GP_HIP(c, hipEventCreateWithFlags(&c->gev[i], hipEventDisableTiming));
+  }
+  hipStream_t s2 = two ? c->side : st;
   GemmP g;
   g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
   const bool sk = ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0;
   if (sk) { g.splits = kSplitK; g.ws = ws; }
+  if (two) { GP_HIP(c, hipEventRecord(c->gev[0], st)); GP_HIP(c, hipStreamWaitEvent(s2, c->gev[0], 0)); }
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.A = Psi2; g.lda = Mp; g.B = c->E; g.ldb = Dp; g.C = c->PsiE; g.ldc = Dp;
@@ -289,9 +299,10 @@ int run_global_step(gp_ctx* c) {
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
   { const int sps = g.splits; if ((Dp / KC) % kSplitK != 0 || Dp < 256) g.splits = 1; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
   g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
-  launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+  launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;
-  launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+  launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+  if (two) { GP_HIP(c, hipEventRecord(c->gev[1], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[1], 0)); }
   GP_HIP(c, hipGetLastError());
   // dFdK currently holds Ki Psi2 Ki; assemble in place is unsafe (reads KPK, writes dFdK at the same index: fine, same thread)
   hipLaunchKernelGGL(assemble_kernel, dim3(1024), dim3(256), 0, st, Ki, P, c->T1, c->dFdK, c->E, c->beta, (double)D, Mp, Dp, c->Bbar,
@@ -307,12 +318,15 @@ int run_global_step(gp_ctx* c) {
   jobs.j[5] = {c->Abar, C, Dp, M, D, GS_SUM_AC};
   jobs.j[6] = {c->Bbar, Psi2, Mp, M, M, GS_SUM_BPSI2};
   double* dpart = c->gs + GS_COUNT + 8;   // [jobs][DOT_BLOCKS]
+  // the traces / scalars and the Kmm parts of the gradients both start from the assembled partials and do not touch each other's outputs
+  if (two) { GP_HIP(c, hipEventRecord(c->gev[2], st)); GP_HIP(c, hipStreamWaitEvent(s2, c->gev[2], 0)); }
   hipLaunchKernelGGL(dots_kernel, dim3(DOT_BLOCKS, jobs.n), dim3(256), 0, st, jobs, dpart);
   hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, jobs, dpart, c->beta, c->sf2, (double)D, (double)c->N_global);
   // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
-  hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, st, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
+  hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
                      c->regime_A ? 1 : 0, c->gK, c->T2);
-  hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, st, c->T2, M, Q, c->gK + (long)M * Q);
+  hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, s2, c->T2, M, Q, c->gK + (long)M * Q);
+  if (two) { GP_HIP(c, hipEventRecord(c->gev[3], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[3], 0)); }
   GP_HIP(c, hipGetLastError());
   c->gs_pending = true;   // scalars and failure flags are read back at the next host synchronisation point (check_global)
   return GP_OK;

@@ -438,13 +438,16 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
   const long n0 = (long)blockIdx.x * a.ppb, n1 = min(a.N, n0 + a.ppb);
   for (int i = tid; i < a.Mp * RT; i += blockDim.x) rt[i] = 0.0;
   __syncthreads();
-  const int lq = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
   for (long n = n0; n < n1; ++n) {
     const double* v2 = V2P + n * QT;                   // wave-uniform
     const double* lrow = LEA + n * a.Mp;
     for (int rd = 0; rd < nrounds; ++rd) {
       const int code = sched[rd * nw + wave];          // wave-uniform: I | J << 16, -1 = idle
       if (code >= 0) {
+        // lane coordinates from an opaque copy of the lane id at their point of use: as loop invariants they were spilled (32 B of scratch per lane)
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int lq = le & 3, lb = (le >> 2) & 3, lk = le >> 4;
         const int I = code & 0xffff, J = code >> 16;
         const bool offd = I != J;
         const int mc = 64 * J + lane;

@@ -215,7 +215,7 @@ eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
 ev = DistributedEvaluator(eng, device=torch.device('cuda', 0), force_collectives=True)
 out = ev.evaluate(False)
 st, gt = ev._tensors()
-assert st.is_cuda and st.dtype == torch.float64 and st.data_ptr() == eng.stats_buffer()[0]
+assert st.is_cuda and st.dtype == torch.float64 and st.data_ptr() == eng.stats_packed_buffer()[0] and gt.data_ptr() == eng.grads_buffer()[0]
 ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=False)
 assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F'])
 assert np.max(np.abs(out['grad_Z'] - ref['grad_Z'])) <= 1e-5 * np.max(np.abs(ref['grad_Z']))

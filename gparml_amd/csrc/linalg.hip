@@ -9,6 +9,7 @@
 #include "potrf128.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace gp {
 
@@ -281,7 +282,10 @@ int run_global_step(gp_ctx* c) {
   // E = P C ; PsiE = Psi2 E ; T1 = E E^T   and, independent of it,   T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki.
   // Every launch here is a handful of 5-12 us products that leave most of the chip idle, so the second chain runs on a side stream (fork /
   // join by events; the small-tile GEMM needs no shared workspace).  Larger problems (> 256 tiles: split-k through the shared workspace) stay serial.
-  const bool two = (long)(Mp / TILE) * (std::max(Mp, Dp) / TILE) <= 256;
+  // (measured, r03: 0.424 -> 0.455 ms at M = 512 and 0.12 -> 0.15 ms at M = 128 with the side stream on -- every cross-stream event edge costs
+  // more than the 5-12 us product it hides; kept behind GPARML_GLOBAL_TWO_STREAMS=1 for the record, off by default)
+  static const bool two_env = [] { const char* e = getenv("GPARML_GLOBAL_TWO_STREAMS"); return e && e[0] == '1'; }();
+  const bool two = two_env && (long)(Mp / TILE) * (std::max(Mp, Dp) / TILE) <= 256;
   if (two && !c->side) {
     GP_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) GP_HIP(c, hipEventCreateWithFlags(&c->gev[i], hipEventDisableTiming));

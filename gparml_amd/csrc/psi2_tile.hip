@@ -83,6 +83,9 @@ __device__ __forceinline__ void mfma444_zero(double& c, double a, double b) {
 // With TXS = 66 the column side's operand reads (16 columns x rows 4 s + {0, 1} per 32-lane group) are conflict-free and the row side's
 // (columns 4 s + {0, 1} x 16 rows) collide in 2 of 32 lanes.
 constexpr int TXS = 66;
+#ifndef GPARML_TILE_FOLD_DEPTH
+#define GPARML_TILE_FOLD_DEPTH 1
+#endif
 
 template <int QT>
 __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
@@ -189,18 +192,20 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
   // table reads per q-quad are asm reads one quad ahead (left to the compiler all 4 NQ loads are hoisted: 100 VGPRs in flight)
   auto fold = [&](const double (&tq)[NQ], double (&G)[NQ], unsigned aZo, unsigned aQt, double* p) -> double {
     const double r = quad_xchg<0xFF>(tq[NQ - 1]);                         // the ones column sits at q = QT - 1 (qq = NQ - 1, li = 3)
-    double tb[2][4];
-    auto rdF = [&](auto qc, double (&t_)[4]) {
-      constexpr int qq = decltype(qc)::value;
-      t_[0] = ds_read64<(4 * qq) * 8>(aZo); t_[1] = ds_read64<(4 * qq) * 8>(aQt);
-      t_[2] = ds_read64<(QT + 4 * qq) * 8>(aQt); t_[3] = ds_read64<(2 * QT + 4 * qq) * 8>(aQt);
+    constexpr int FD = GPARML_TILE_FOLD_DEPTH;            // q-quads requested ahead (an LDS round trip is ~4 quads of fold arithmetic)
+    double tb[FD + 1][4];
+    auto rdF = [&](auto qc) {
+      constexpr int qq = decltype(qc)::value, sl = qq % (FD + 1);
+      tb[sl][0] = ds_read64<(4 * qq) * 8>(aZo); tb[sl][1] = ds_read64<(4 * qq) * 8>(aQt);
+      tb[sl][2] = ds_read64<(QT + 4 * qq) * 8>(aQt); tb[sl][3] = ds_read64<(2 * QT + 4 * qq) * 8>(aQt);
     };
     __builtin_amdgcn_sched_barrier(0);
-    rdF(IC<0>{}, tb[0]);
+    static_for<0, (FD < NQ ? FD : NQ)>([&](auto qc) { rdF(qc); });
     static_for<0, NQ>([&](auto qc) {
-      constexpr int qq = decltype(qc)::value, cur = qq & 1;
-      if constexpr (qq + 1 < NQ) { rdF(IC<qq + 1>{}, tb[cur ^ 1]); lgkm_wait<4>(); }
-      else lgkm_wait<0>();
+      constexpr int qq = decltype(qc)::value, cur = qq % (FD + 1);
+      if constexpr (qq + FD < NQ) rdF(IC<qq + FD>{});
+      constexpr int ahead = (NQ - 1 - qq) < FD ? (NQ - 1 - qq) : FD;
+      lgkm_wait<4 * ahead>();
       __builtin_amdgcn_sched_barrier(0);
       const double z = tb[cur][0], kap = tb[cur][1], c1 = tb[cur][2], c2 = tb[cur][3];
       G[qq] = fma(tq[qq], kap, fma(r, fma(-z, c1, c2), G[qq]));

@@ -1006,6 +1006,201 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
   }
 }
 
+// General phase 2 on the eight-wave structure (r03; replaces the four-wave p2_kernel<true>: 256 VGPRs + 320 B of scratch, 0.19 of peak): any
+// number of feature columns, with the per-point m-contraction HZ = W Zaug (embedding gradients, partial_terms.py:367-431).  The k-loop is
+// p2_fast8_kernel's (64 x 32 wave tiles, LDS-DMA staging, explicit ds_read_b64 operand reads); the epilogue keeps W = G o Psi1 in the 32
+// accumulator registers and sends it through a per-wave LDS slab 16 rows at a time, once per group of four feature quads:
+//   n-contraction  R[m][c]  += sum_n W[n][m] Xa[n][c]      A = slab read transposed (16 m x 4 n), B = Xa rows from global
+//   m-contraction  HZ[n][c]  = sum_m W[n][m] Zaug[m][c]    A = slab read as stored (16 n x 4 m), B = Zaug rows; partial over the wave's 32
+//                  columns: four partial arrays per 128-column tile in HZp (the two waves of a quadrant own different columns)
+constexpr int GSLD = 34;     // slab row stride (doubles): 16 x 32 values per wave
+constexpr int GGRP = 2;      // feature quads per pass (8 columns): four do not fit 128 VGPRs next to the 32 accumulators
+template <bool PPATH>
+__global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
+  if (slice >= p.S) return;
+  __shared__ __attribute__((aligned(16))) double lds[P2W8_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  const int quad = wave & 3, half = wave >> 2;
+  const int wr = quad >> 1, wc = quad & 1;
+  const int wrow0 = wr * WT, wcol0 = wc * WT + 32 * half;
+  const int nc = p.kend - p.kbeg;
+  const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
+  const unsigned lds_base = lds_byte_addr(lds);
+  // per wave a private 1280-double area: [0, 512) Psi1 slab A | [512, 1056) the W slab, which doubles as Psi1 slab B while W is being formed
+  double* const area = lds + wave * 1280;
+  double* const slab = area + 512;
+  auto chunk_dma = [&](double* buf, const double* a, const double* b) {
+    int ld_ = lane;
+    asm volatile("" : "+v"(ld_));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int I = wave * 2 + i;
+      const int row = swap03(I * 8 + (ld_ >> 3));
+      glds16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(a) + (unsigned)(8 * (row * (int)p.ld + 2 * ((ld_ & 7) ^ (row & 7))))),
+             buf + I * 8 * KC);
+      glds16(b + (long)I * p.Mp + 2u * ld_, buf + TILE_LDS_DOUBLES + I * LDS_RC);
+    }
+  };
+  const int ngx = (p.CXp / 4 + GGRP - 1) / GGRP, ngz = (p.CZp / 4 + GGRP - 1) / GGRP;
+  for (int nt = t0; nt < t1; ++nt) {
+    const long n0 = (long)nt * TILE;
+    const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
+    const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;
+    // the k-loop's lane offsets are recomputed per tile from an opaque copy of the lane id: held across the epilogue they are spilled
+    int lo_ = lane;
+    asm volatile("" : "+v"(lo_));
+    const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lo_);
+    double acc[4][8];
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[ar][j] = 0.0;
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);                  // asm-defined zeros: no rematerialised v_mov in front of an asm MFMA
+    chunk_dma(lds, Ab, Bb);
+    dma_wait();
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      const int cur = c & 1;
+      auto issue_next = [&]() { if (c + 1 < nc) chunk_dma(lds + (cur ^ 1) * 4608, Ab + (long)(c + 1) * KC, Bb + (long)(c + 1) * KC * p.Mp); };
+      if (half == 0) issue_next();
+      const unsigned sbase_b = lds_base + (unsigned)cur * (4608u * 8u);
+      const unsigned aB = sbase_b + TILE_LDS_DOUBLES * 8 + 8u * (unsigned)ofs.b[0];
+      static_for<0, KC / 4>([&](auto k4c) {
+        constexpr int k4 = decltype(k4c)::value;
+        if constexpr (k4 == 2) { if (half == 1) issue_next(); }
+        const unsigned aA = sbase_b + 8u * (unsigned)ofs.a[k4];
+        double a[4], b[8];
+        a[0] = ds_read64<0>(aA); a[1] = ds_read64<2048>(aA); a[2] = ds_read64<4096>(aA); a[3] = ds_read64<6144>(aA);
+        static_for<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; b[j] = ds_read64<k4 * 4 * LDS_RC * 8 + 32 * j>(aB); });
+        static_for<0, 8>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          lgkm_wait<7 - j>();
+#pragma unroll
+          for (int ar = 0; ar < 4; ++ar) mfma444_acc(acc[ar][j], a[ar], b[j]);
+        });
+      });
+      dma_wait();
+      __syncthreads();
+    }
+    mfma_drain(acc[3][7]);
+#pragma unroll
+    for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);
+    // ---- epilogue: the staging buffers are free.  Lane coordinates from an opaque copy (not held across the k-loop).
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int lr = le & 15, lk = le >> 4, lj = le & 3;
+    const int srow = 4 * ((le >> 2) & 3) + (le >> 4);
+    // W = G o Psi1 in the accumulator layout (row 16 ar + srow, column 4 bc + lj of the wave's 64 x 32 block).  The wave's Psi1 block
+    // arrives by LDS-DMA in four 16-row slabs, two in flight (register-staged loads of the 32 values do not fit next to the accumulators:
+    // the compiler serialised them, one L2 round trip per value); slab image permuted as in p2_fast8_kernel (pair p of row r at p ^ 2 g(r))
+    {
+      const int sg = slab_g(srow), sbase = srow * 32 + lj;
+      const int dpair = (le & 15) ^ ((lk & 1) << 3);
+      const double* Ktile = p.Kaug + (n0 + wrow0) * p.ld + (long)mt * TILE + wcol0;
+      auto slab_dma = [&](int ar, double* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          glds16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Ktile) +
+                                                 (unsigned)(8 * ((16 * ar + 4 * i + lk) * (int)p.ld + 2 * (dpair ^ (2 * i))))), dst + i * 128);
+      };
+      slab_dma(0, area);
+      slab_dma(1, slab);
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar) {
+        double* ks = (ar & 1) ? slab : area;
+        if (ar < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // slab ar has landed; slab ar + 1 (4 DMAs) may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int bc = 0; bc < 8; ++bc) acc[ar][bc] *= ks[sbase + 4 * (bc ^ sg)];
+        acc_fence8(acc[ar]);
+        if (ar < 2) {
+          __builtin_amdgcn_sched_barrier(0);                            // the slab's values are in the accumulators: the buffer is free again
+          slab_dma(ar + 2, ks);
+        }
+      }
+    }
+    // ---- n-contraction: R[m][c] += sum_n W[n][m] Xa[n][c]; this wave owns rows [wcol0, wcol0 + 32) of its (slice, wave-row, m-tile) block
+    double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
+    for (int g = 0; g < ngx; ++g) {
+      double r[2][GGRP];
+#pragma unroll
+      for (int am = 0; am < 2; ++am)
+#pragma unroll
+        for (int j = 0; j < GGRP; ++j) r[am][j] = 0.0;
+      acc_fence<GGRP>(r[0]); acc_fence<GGRP>(r[1]);
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar) {
+#pragma unroll
+        for (int bc = 0; bc < 8; ++bc) slab[srow * GSLD + 4 * bc + lj] = acc[ar][bc];
+        const double* xrow = p.Xa + (n0 + wrow0 + 16 * ar) * p.CXp + 4 * GGRP * g + lj;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          double a[2], b[GGRP];
+#pragma unroll
+          for (int am = 0; am < 2; ++am) a[am] = slab[(4 * k4 + lk) * GSLD + 16 * am + lr];
+#pragma unroll
+          for (int j = 0; j < GGRP; ++j) b[j] = (4 * (GGRP * g + j) < p.CXp) ? xrow[(long)(4 * k4 + lk) * p.CXp + 4 * j] : 0.0;
+#pragma unroll
+          for (int am = 0; am < 2; ++am)
+#pragma unroll
+            for (int j = 0; j < GGRP; ++j) mfma444_acc(r[am][j], a[am], b[j]);
+        }
+      }
+      mfma_drain(r[1][GGRP - 1]);
+      acc_fence<GGRP>(r[0]); acc_fence<GGRP>(r[1]);
+#pragma unroll
+      for (int am = 0; am < 2; ++am)
+#pragma unroll
+        for (int j = 0; j < GGRP; ++j) {
+          const int col = 4 * (GGRP * g + j) + lj;
+          if (col < p.CXp) {
+            double* dst = Rmine + (long)(16 * am + srow) * p.CXp + col;
+            *dst = ((nt == t0) ? 0.0 : *dst) + r[am][j];
+          }
+        }
+    }
+    // ---- m-contraction: HZ[n][c] = sum_m W[n][m] Zaug[m][c] over this wave's 32 columns
+    if (PPATH) {
+      double* hz = p.HZp + ((long)(mt * 4 + 2 * wc + half) * p.Np + n0 + wrow0) * p.CZp;
+      for (int g = 0; g < ngz; ++g) {
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) {
+          // even and odd k-steps accumulate separately: an accumulator is reused every 2 GGRP = 4 MFMAs (the asm MFMAs get no automatic
+          // wait states; at a distance of two the dependent accumulation read a stale value)
+          double h[2][GGRP];
+#pragma unroll
+          for (int j = 0; j < GGRP; ++j) { h[0][j] = 0.0; h[1][j] = 0.0; }
+          acc_fence<GGRP>(h[0]); acc_fence<GGRP>(h[1]);
+#pragma unroll
+          for (int bc = 0; bc < 8; ++bc) slab[srow * GSLD + 4 * bc + lj] = acc[ar][bc];
+          const double* zrow = p.Zaug + ((long)mt * TILE + wcol0) * p.CZp + 4 * GGRP * g + lj;
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) {
+            const double a = slab[lr * GSLD + 4 * k4 + lk];
+#pragma unroll
+            for (int j = 0; j < GGRP; ++j) {
+              const double b = (4 * (GGRP * g + j) < p.CZp) ? zrow[(long)(4 * k4 + lk) * p.CZp + 4 * j] : 0.0;
+              mfma444_acc(h[k4 & 1][j], a, b);
+            }
+          }
+          mfma_drain(h[1][GGRP - 1]);
+          acc_fence<GGRP>(h[0]); acc_fence<GGRP>(h[1]);
+#pragma unroll
+          for (int j = 0; j < GGRP; ++j) {
+            const int col = 4 * (GGRP * g + j) + lj;
+            if (col < p.CZp) hz[(long)(16 * ar + srow) * p.CZp + col] = h[0][j] + h[1][j];
+          }
+        }
+      }
+    }
+    __syncthreads();   // the slabs live in the staging buffers the next tile's DMA overwrites
+  }
+}
+
 // grad_alpha's mu^2 term from the row sums: out[block][q] = -1/2 sum_{n in block} (sum_p H[p][n]) mu_nq^2   (fixed tree)
 __global__ void __launch_bounds__(256) p2_ga_kernel(const double* __restrict__ H, int nparts, long N, long Np, int Q,
                                                     const double* __restrict__ mu, double* __restrict__ gapart) {
@@ -1122,7 +1317,7 @@ int run_phase2(gp_ctx* c) {
   const int nrb = (c->Q + 1 + 3) / 4;                // fast path: feature columns [mu (Q) | 1] in groups of four
   int hparts = 0;                                    // row-sum partial arrays the fast kernels leave in HZp
   (void)hipEventRecord(c->ev[12], c->stream);
-  if (ppath) hipLaunchKernelGGL((p2_kernel<true>), dim3(blocks), dim3(256), 0, c->stream, p);
+  if (ppath) hipLaunchKernelGGL((p2_gen8_kernel<true>), dim3(blocks), dim3(512), 0, c->stream, p);
   else if (nrb <= 3) {
     p.gapart = c->hgpart;
     GP_HIP(c, hipMemsetAsync(c->hgpart, 0, (size_t)blocks * 8 * 4 * nrb * sizeof(double), c->stream));   // blocks past the last slice exit early
@@ -1152,7 +1347,8 @@ int run_phase2(gp_ctx* c) {
   GP_HIP(c, hipGetLastError());
   if (ppath) {
     PtArgs a;
-    a.HZp = c->HZp; a.nparts = 2 * p.MT; a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CZp = c->CZp; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
+    a.HZp = c->HZp; a.nparts = 4 * p.MT;        // p2_gen8_kernel: one partial array per 32 inducing columns
+    a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CZp = c->CZp; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
     a.gmu = c->gXmu; a.gS = c->gXs; a.gapart = c->gapart; a.regimeA = c->regime_A ? 1 : 0;
     hipLaunchKernelGGL(point_kernel, dim3(c->ga_blocks), dim3(256), 256 * sizeof(double), c->stream, a);
     GP_HIP(c, hipGetLastError());

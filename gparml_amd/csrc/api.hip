@@ -145,7 +145,7 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   // phase 2
   c->p2_slices = std::max(1, std::min<int>(8 * std::max(1, 64 / mt), (int)(Np / TILE)));
   A(&c->Rpart, (size_t)2 * (c->p2_slices + 8) * Mp * c->CXp);
-  A(&c->HZp, (size_t)(Mp / 32) * Np * c->CZp);      // p2_gen8_kernel: per-point partials of every 32 inducing columns
+  A(&c->HZp, (size_t)(Mp / TILE) * Np * c->CZp);    // p2_gen8_kernel: per-point partials, one array per 128 inducing columns
   A(&c->gXmu, (size_t)N_s * Q); A(&c->gXs, (size_t)N_s * Q);
   c->ga_blocks = blocks_for(Np);
   A(&c->gapart, (size_t)c->ga_blocks * Q);

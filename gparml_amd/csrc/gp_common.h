@@ -117,7 +117,7 @@ struct gp_ctx {
   // phase 2
   double* Rpart = nullptr;    // [p2_slices][Mp][CXp]
   int p2_slices = 0;
-  double* HZp = nullptr;      // [Mp/32][Np][CZp] per-point partials (one array per 32 inducing columns)
+  double* HZp = nullptr;      // [Mp/128][Np][CZp] per-point partials (one array per 128 inducing columns)
   double* gXmu = nullptr;     // [N][Q]
   double* gXs = nullptr;      // [N][Q]
   double* gapart = nullptr;   // [blocks][Q] per-block alpha partial sums from the per-point kernel

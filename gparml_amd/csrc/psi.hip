@@ -547,132 +547,13 @@ int run_phase1(gp_ctx* c) {
 struct P2Args {
   const double* Kaug; long ld; const double* Bm; const double* Xa; const double* Zaug;
   double* Rpart; double* HZp;
-  int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend; long Np;
+  int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend, klast; long Np;   // klast: k-steps (of 4) of the final chunk that hold real Y columns
   double* gapart;   // eight-wave fast kernel: [blocks * 8][4 NRB] per-wave partials of grad_alpha's mu^2 term
 };
 
 constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
 constexpr int GRP = 6;        // feature columns are processed 24 at a time (6 B registers)
 
-template <bool PPATH>
-__global__ void __launch_bounds__(256, 2) p2_kernel(P2Args p) {
-  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
-  if (slice >= p.S) return;
-  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int wrow0 = wr * WT, wcol0 = wc * WT;
-  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
-  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4);   // row inside a 16-row group held by this lane's accumulators
-  double* slab = &lds[0][0][0] + wave * (16 * SLAB_LD);
-  const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
-  const int nc = p.kend - p.kbeg;
-  const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
-  const int ngx = (p.CXp / 4 + GRP - 1) / GRP, ngz = (p.CZp / 4 + GRP - 1) / GRP;
-  double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
-  for (int nt = t0; nt < t1; ++nt) {
-    const long n0 = (long)nt * TILE;
-    const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;                  // rows n, k contiguous
-    const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;         // rows k, m contiguous
-    Acc acc;
-    acc.zero();
-    tile_dma<K_CONTIG>(lds[0][0], Ab, p.ld, wave, lane);
-    tile_dma<FREE_CONTIG>(lds[0][1], Bb, p.Mp, wave, lane);
-    dma_wait();
-    __syncthreads();
-    for (int c = 0; c < nc; ++c) {
-      const int cur = c & 1;
-      if (c + 1 < nc) {
-        tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)(c + 1) * KC, p.ld, wave, lane);
-        tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)(c + 1) * KC * p.Mp, p.Mp, wave, lane);
-      }
-      mma_chunk<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
-      dma_wait();
-      __syncthreads();
-    }
-    acc.drain();
-    // W = G o Psi1 (same element positions as the accumulators)
-#pragma unroll
-    for (int ar = 0; ar < 4; ++ar) {
-      const double* krow = p.Kaug + (n0 + wrow0 + 16 * ar + srow) * p.ld + (long)mt * TILE + wcol0 + lj;
-#pragma unroll
-      for (int bc = 0; bc < 16; ++bc) acc.v[ar][bc] *= krow[4 * bc];
-    }
-    // ---- n-contraction: R[m][c] += sum_n W[n][m] Xa[n][c]
-    for (int g = 0; g < ngx; ++g) {
-      double r[4][GRP];
-#pragma unroll
-      for (int am = 0; am < 4; ++am)
-#pragma unroll
-        for (int bc = 0; bc < GRP; ++bc) r[am][bc] = 0.0;
-#pragma unroll
-      for (int ar = 0; ar < 4; ++ar) {
-#pragma unroll
-        for (int bc = 0; bc < 16; ++bc) slab[srow * SLAB_LD + 4 * bc + lj] = acc.v[ar][bc];
-        const double* xrow = p.Xa + (n0 + wrow0 + 16 * ar) * p.CXp + 4 * GRP * g + lj;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          double a[4], b[GRP];
-#pragma unroll
-          for (int am = 0; am < 4; ++am) a[am] = slab[(4 * k4 + lk) * SLAB_LD + 16 * am + lr];
-#pragma unroll
-          for (int bc = 0; bc < GRP; ++bc) b[bc] = (4 * (GRP * g + bc) < p.CXp) ? xrow[(long)(4 * k4 + lk) * p.CXp + 4 * bc] : 0.0;
-#pragma unroll
-          for (int am = 0; am < 4; ++am)
-#pragma unroll
-            for (int bc = 0; bc < GRP; ++bc) mfma444_acc(r[am][bc], a[am], b[bc]);
-        }
-      }
-      mfma_drain(r[3][GRP - 1]);
-#pragma unroll
-      for (int am = 0; am < 4; ++am) acc_fence<GRP>(r[am]);
-      // this wave owns rows [wcol0, wcol0+64) of its (slice, wave-row, m-tile) block of Rpart: plain read-modify-write
-#pragma unroll
-      for (int am = 0; am < 4; ++am)
-#pragma unroll
-        for (int bc = 0; bc < GRP; ++bc) {
-          const int col = 4 * (GRP * g + bc) + lj;
-          if (col < p.CXp) {
-            double* dst = Rmine + (long)(16 * am + srow) * p.CXp + col;
-            *dst = ((nt == t0) ? 0.0 : *dst) + r[am][bc];
-          }
-        }
-    }
-    // ---- m-contraction: HZ[n][c] = sum_m W[n][m] Zaug[m][c]  (this wave's 64 columns only; partials summed later)
-    if (PPATH) {
-      double* hz = p.HZp + ((long)(mt * 2 + wc) * p.Np + n0 + wrow0) * p.CZp;
-      for (int g = 0; g < ngz; ++g) {
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar) {
-          double h[GRP];
-#pragma unroll
-          for (int bc = 0; bc < GRP; ++bc) h[bc] = 0.0;
-#pragma unroll
-          for (int bc = 0; bc < 16; ++bc) slab[srow * SLAB_LD + 4 * bc + lj] = acc.v[ar][bc];
-          const double* zrow = p.Zaug + ((long)mt * TILE + wcol0) * p.CZp + 4 * GRP * g + lj;
-#pragma unroll 4
-          for (int k4 = 0; k4 < 16; ++k4) {
-            const double a = slab[lr * SLAB_LD + 4 * k4 + lk];
-#pragma unroll
-            for (int bc = 0; bc < GRP; ++bc) {
-              const double b = (4 * (GRP * g + bc) < p.CZp) ? zrow[(long)(4 * k4 + lk) * p.CZp + 4 * bc] : 0.0;
-              mfma444_acc(h[bc], a, b);
-            }
-          }
-          mfma_drain(h[GRP - 1]);
-          acc_fence<GRP>(h);
-#pragma unroll
-          for (int bc = 0; bc < GRP; ++bc) {
-            const int col = 4 * (GRP * g + bc) + lj;
-            if (col < p.CZp) hz[(long)(16 * ar + srow) * p.CZp + col] = h[bc];
-          }
-        }
-      }
-    }
-    __syncthreads();   // slabs live in the staging buffers the next tile's DMA overwrites
-  }
-}
 
 // Fast variants for the fixed-embedding regime (no per-point outputs), Q + 1 <= 4 * NRB <= 24.  Per-point features are
 // Xa = [mu (Q) | 1 | 0..]: R[m][:] = sum_n W[n][m] Xa[n][:] gives W^T mu and W^T 1 (grad_Z, and the z-dependent terms of
@@ -924,9 +805,11 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
       // operand reads as explicit ds_read_b64 (see mma_f64.h): 4 A + 8 B per k-step, MFMAs start as soon as A and the first B landed
       const unsigned sbase_b = lds_base + (unsigned)cur * (4608u * 8u);
       const unsigned aB = sbase_b + TILE_LDS_DOUBLES * 8 + 8u * (unsigned)ofs.b[0];
+      const bool tail = (c == nc - 1);
       static_for<0, KC / 4>([&](auto k4c) {
         constexpr int k4 = decltype(k4c)::value;
         if constexpr (k4 == 2) { if (half == 1) issue_next(); }
+        if (k4 > 0 && tail && k4 >= p.klast) return;   // k-steps past the last real Y column multiply zeros
         const unsigned aA = sbase_b + 8u * (unsigned)ofs.a[k4];
         double a[4], b[8];
         a[0] = ds_read64<0>(aA); a[1] = ds_read64<2048>(aA); a[2] = ds_read64<4096>(aA); a[3] = ds_read64<6144>(aA);
@@ -1008,13 +891,15 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
 
 // General phase 2 on the eight-wave structure (r03; replaces the four-wave p2_kernel<true>: 256 VGPRs + 320 B of scratch, 0.19 of peak): any
 // number of feature columns, with the per-point m-contraction HZ = W Zaug (embedding gradients, partial_terms.py:367-431).  The k-loop is
-// p2_fast8_kernel's (64 x 32 wave tiles, LDS-DMA staging, explicit ds_read_b64 operand reads); the epilogue keeps W = G o Psi1 in the 32
-// accumulator registers and sends it through a per-wave LDS slab 16 rows at a time, once per group of four feature quads:
-//   n-contraction  R[m][c]  += sum_n W[n][m] Xa[n][c]      A = slab read transposed (16 m x 4 n), B = Xa rows from global
-//   m-contraction  HZ[n][c]  = sum_m W[n][m] Zaug[m][c]    A = slab read as stored (16 n x 4 m), B = Zaug rows; partial over the wave's 32
-//                  columns: four partial arrays per 128-column tile in HZp (the two waves of a quadrant own different columns)
+// p2_fast8_kernel's (64 x 32 wave tiles, LDS-DMA staging, explicit ds_read_b64 operand reads).  The epilogue keeps W = G o Psi1 in the 32
+// accumulator registers (Psi1 arrives by LDS-DMA in 16-row slabs) and contracts it twice:
+//   n-contraction  R[m][c]  += sum_n W[n][m] Xa[n][c]      straight from the registers: the accumulator layout IS the B operand of the
+//                  four-block MFMA, the blocks' partial sums are added through LDS (no transposed copy of W)
+//   m-contraction  HZ[n][c]  = sum_m W[n][m] Zaug[m][c]    W through a per-wave LDS slab pair (32 rows), read back transposed as the A
+//                  operand of v_mfma_f64_16x16x4; the four 32-column partials of a row are exchanged through LDS and added in column
+//                  order, so HZp holds one partial array per 128-column tile
+// 125-128 VGPRs, no scratch; configs[2] shape with free embeddings (1e5 points): 918 -> 403 us, point_kernel 241 -> 68 us.
 constexpr int GSLD = 34;     // slab row stride (doubles): 16 x 32 values per wave
-constexpr int GGRP = 2;      // feature quads per pass (8 columns): four do not fit 128 VGPRs next to the 32 accumulators
 template <bool PPATH>
 __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -1044,7 +929,6 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
       glds16(b + (long)I * p.Mp + 2u * ld_, buf + TILE_LDS_DOUBLES + I * LDS_RC);
     }
   };
-  const int ngx = (p.CXp / 4 + GGRP - 1) / GGRP, ngz = (p.CZp / 4 + GGRP - 1) / GGRP;
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
@@ -1069,9 +953,11 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
       if (half == 0) issue_next();
       const unsigned sbase_b = lds_base + (unsigned)cur * (4608u * 8u);
       const unsigned aB = sbase_b + TILE_LDS_DOUBLES * 8 + 8u * (unsigned)ofs.b[0];
+      const bool tail = (c == nc - 1);
       static_for<0, KC / 4>([&](auto k4c) {
         constexpr int k4 = decltype(k4c)::value;
         if constexpr (k4 == 2) { if (half == 1) issue_next(); }
+        if (k4 > 0 && tail && k4 >= p.klast) return;   // k-steps past the last real Y column multiply zeros
         const unsigned aA = sbase_b + 8u * (unsigned)ofs.a[k4];
         double a[4], b[8];
         a[0] = ds_read64<0>(aA); a[1] = ds_read64<2048>(aA); a[2] = ds_read64<4096>(aA); a[3] = ds_read64<6144>(aA);
@@ -1097,6 +983,9 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
     // W = G o Psi1 in the accumulator layout (row 16 ar + srow, column 4 bc + lj of the wave's 64 x 32 block).  The wave's Psi1 block
     // arrives by LDS-DMA in four 16-row slabs, two in flight (register-staged loads of the 32 values do not fit next to the accumulators:
     // the compiler serialised them, one L2 round trip per value); slab image permuted as in p2_fast8_kernel (pair p of row r at p ^ 2 g(r))
+#if defined(GPARML_GEN8_ABLATE) && (GPARML_GEN8_ABLATE & 4)
+    if (p.MT < 0)
+#endif
     {
       const int sg = slab_g(srow), sbase = srow * 32 + lj;
       const int dpair = (le & 15) ^ ((lk & 1) << 3);
@@ -1123,81 +1012,137 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
         }
       }
     }
-    // ---- n-contraction: R[m][c] += sum_n W[n][m] Xa[n][c]; this wave owns rows [wcol0, wcol0 + 32) of its (slice, wave-row, m-tile) block
-    double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
-    for (int g = 0; g < ngx; ++g) {
-      double r[2][GGRP];
+#ifdef GPARML_GEN8_ABLATE   // timing experiments only (results wrong): bit 0 = no m-contraction, bit 1 = no n-contraction, bit 2 = no Psi1 product
+    if (p.MT < 0) {
 #pragma unroll
-      for (int am = 0; am < 2; ++am)
+      for (int ar = 0; ar < 4; ++ar)
 #pragma unroll
-        for (int j = 0; j < GGRP; ++j) r[am][j] = 0.0;
-      acc_fence<GGRP>(r[0]); acc_fence<GGRP>(r[1]);
-#pragma unroll
-      for (int ar = 0; ar < 4; ++ar) {
-#pragma unroll
-        for (int bc = 0; bc < 8; ++bc) slab[srow * GSLD + 4 * bc + lj] = acc[ar][bc];
-        const double* xrow = p.Xa + (n0 + wrow0 + 16 * ar) * p.CXp + 4 * GGRP * g + lj;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          double a[2], b[GGRP];
-#pragma unroll
-          for (int am = 0; am < 2; ++am) a[am] = slab[(4 * k4 + lk) * GSLD + 16 * am + lr];
-#pragma unroll
-          for (int j = 0; j < GGRP; ++j) b[j] = (4 * (GGRP * g + j) < p.CXp) ? xrow[(long)(4 * k4 + lk) * p.CXp + 4 * j] : 0.0;
-#pragma unroll
-          for (int am = 0; am < 2; ++am)
-#pragma unroll
-            for (int j = 0; j < GGRP; ++j) mfma444_acc(r[am][j], a[am], b[j]);
-        }
-      }
-      mfma_drain(r[1][GGRP - 1]);
-      acc_fence<GGRP>(r[0]); acc_fence<GGRP>(r[1]);
-#pragma unroll
-      for (int am = 0; am < 2; ++am)
-#pragma unroll
-        for (int j = 0; j < GGRP; ++j) {
-          const int col = 4 * (GGRP * g + j) + lj;
-          if (col < p.CXp) {
-            double* dst = Rmine + (long)(16 * am + srow) * p.CXp + col;
-            *dst = ((nt == t0) ? 0.0 : *dst) + r[am][j];
-          }
-        }
+        for (int bc = 0; bc < 8; ++bc) p.HZp[(ar * 8 + bc) * 64 + le] = acc[ar][bc];
     }
-    // ---- m-contraction: HZ[n][c] = sum_m W[n][m] Zaug[m][c] over this wave's 32 columns
-    if (PPATH) {
-      double* hz = p.HZp + ((long)(mt * 4 + 2 * wc + half) * p.Np + n0 + wrow0) * p.CZp;
-      for (int g = 0; g < ngz; ++g) {
+#endif
+    // ---- n-contraction, straight from the accumulators: R[m][c] += sum_n W[n][m] Xa[n][c], this wave's 32 columns m.
+    // v_mfma_f64_4x4x4_4b computes four independent 4x4x4 blocks; lane l = (k = l >> 4, block b = (l >> 2) & 3, j = l & 3) holds
+    // W[16 ar + 4 b + k][4 bc + j] in acc[ar][bc] -- exactly the B operand B_b[k][j] of block b.  With A_b[i][k] = Xa[16 ar + 4 b + k][c0 + i]
+    // (lane (i = l & 3, b, k): the same row 16 ar + srow, column c0 + lj) block b accumulates its four points' share of R[4 bc + j][c0 + i];
+    // the four block partials are added through the wave's LDS area.  No transposed copy of W is needed.
+#if defined(GPARML_GEN8_ABLATE) && (GPARML_GEN8_ABLATE & 2)
+    if (p.MT < 0)
+#endif
+    {
+      double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * p.CXp;
+      const double* xbase = p.Xa + (n0 + wrow0) * p.CXp;          // uniform bases + 32-bit lane offsets (scalar-base addressing)
+      const int xo = srow * p.CXp + lj;
+      const int nqx = p.CXp / 4, bsel = (le >> 2) & 3;
+      const int ro = (8 * bsel + lj) * p.CXp + lk;
+      const bool first = (nt == t0);
+      // (two quads in flight -- one in the MFMA pipe while the other's partials go through LDS -- needs 16 more VGPRs than there are: the
+      // compiler spilled seven accumulators; the loads below are issued a quad ahead instead)
+      double x[4], xn[4];
 #pragma unroll
-        for (int ar = 0; ar < 4; ++ar) {
-          // even and odd k-steps accumulate separately: an accumulator is reused every 2 GGRP = 4 MFMAs (the asm MFMAs get no automatic
-          // wait states; at a distance of two the dependent accumulation read a stale value)
-          double h[2][GGRP];
+      for (int ar = 0; ar < 4; ++ar) { x[ar] = xbase[xo + 16 * ar * p.CXp]; xn[ar] = 0.0; }
+      for (int q = 0; q < nqx; ++q) {
+        double d[8];
 #pragma unroll
-          for (int j = 0; j < GGRP; ++j) { h[0][j] = 0.0; h[1][j] = 0.0; }
-          acc_fence<GGRP>(h[0]); acc_fence<GGRP>(h[1]);
+        for (int bc = 0; bc < 8; ++bc) d[bc] = 0.0;
+        acc_fence8(d);
+        // this lane finishes R[4 (2 bsel + s) + lj][4 q + lk], s = 0, 1
+        double* dst = Rmine + (ro + 4 * q);
+        double o0 = 0.0, o1 = 0.0;
+        if (!first) { o0 = dst[0]; o1 = dst[4 * p.CXp]; }
+        if (q + 1 < nqx) {
 #pragma unroll
-          for (int bc = 0; bc < 8; ++bc) slab[srow * GSLD + 4 * bc + lj] = acc[ar][bc];
-          const double* zrow = p.Zaug + ((long)mt * TILE + wcol0) * p.CZp + 4 * GGRP * g + lj;
+          for (int ar = 0; ar < 4; ++ar) xn[ar] = xbase[xo + 16 * ar * p.CXp + 4 * (q + 1)];
+        }
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar)
+#pragma unroll
+          for (int bc = 0; bc < 8; ++bc) mfma444_acc(d[bc], x[ar], acc[ar][bc]);
+        mfma_drain(d[7]);
+        acc_fence8(d);
+#pragma unroll
+        for (int bc = 0; bc < 8; ++bc) area[bc * 66 + le] = d[bc];
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          v0 += area[(2 * bsel) * 66 + 16 * lk + 4 * b + lj];
+          v1 += area[(2 * bsel + 1) * 66 + 16 * lk + 4 * b + lj];
+        }
+        dst[0] = o0 + v0;
+        dst[4 * p.CXp] = o1 + v1;
+#pragma unroll
+        for (int ar = 0; ar < 4; ++ar) x[ar] = xn[ar];
+      }
+    }
+    // ---- m-contraction: HZ[n][c] = sum_m W[n][m] Zaug[m][c].  W goes through the wave's LDS area 32 rows at a time (the transposed
+    // read is the A operand of v_mfma_f64_16x16x4: lane (row l & 15, k l >> 4)); B = Zaug rows, 16 feature columns per instruction with
+    // 64 distinct values (lane (k l >> 4, column l & 15)), shared by the two 16-row slabs.  Each wave contracts its own 32 columns; the four
+    // partials of a 64-row half-tile are exchanged through LDS and added in column order, so HZp holds ONE array per 128-column tile.
+#if defined(GPARML_GEN8_ABLATE) && (GPARML_GEN8_ABLATE & 1)
+    if (p.MT < 0)
+#else
+    if (PPATH)
+#endif
+    {
+      typedef double v4d __attribute__((ext_vector_type(4)));
+      int lm = lane;                                        // fresh lane coordinates: carried over from above they are spilled
+      asm volatile("" : "+v"(lm));
+      const int lr = lm & 15, lk = lm >> 4, lj = lm & 3, le = lm;
+      const int srow = 4 * ((lm >> 2) & 3) + (lm >> 4);
+      const int ng = (p.CZp + 15) / 16;
+      const double* zbase = p.Zaug + ((long)mt * TILE + wcol0) * p.CZp + lk * p.CZp;
+      const int wi = 2 * wc + half;
+      double bn[8];
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) bn[k4] = zbase[4 * k4 * p.CZp + min(lr, p.CZp - 1)];
+      const int rrow = 8 * wi + (le >> 3), rcol = 2 * (le & 7);
+      int xpar = 0;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        if (pr == 1) __syncthreads();   // the other waves are done with this wave's exchange buffers, which the slab writes overwrite
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int bc = 0; bc < 8; ++bc) area[t * 544 + srow * GSLD + 4 * bc + lj] = acc[2 * pr + t][bc];
+        double a[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) a[t][k4] = area[t * 544 + lr * GSLD + 4 * k4 + lk];
+        for (int g = 0; g < ng; ++g) {
+          double b[8];
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) b[k4] = bn[k4];
+          {                                                 // the next group's rows (the other slab pair starts over at group 0) load under the MFMAs
+            const int gn = (g + 1 < ng) ? g + 1 : 0;
+            const int col = min(16 * gn + lr, p.CZp - 1);   // columns past CZp: results discarded
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) bn[k4] = zbase[4 * k4 * p.CZp + col];
+          }
+          v4d D0 = {0.0, 0.0, 0.0, 0.0}, D1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int k4 = 0; k4 < 8; ++k4) {
-            const double a = slab[lr * GSLD + 4 * k4 + lk];
-#pragma unroll
-            for (int j = 0; j < GGRP; ++j) {
-              const double b = (4 * (GGRP * g + j) < p.CZp) ? zrow[(long)(4 * k4 + lk) * p.CZp + 4 * j] : 0.0;
-              mfma444_acc(h[k4 & 1][j], a, b);
-            }
+            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][k4], b[k4], D0, 0, 0, 0);
+            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][k4], b[k4], D1, 0, 0, 0);
           }
-          mfma_drain(h[1][GGRP - 1]);
-          acc_fence<GGRP>(h[0]); acc_fence<GGRP>(h[1]);
+          double* xb = area + xpar * 512;                   // exchange buffer [32 rows][16 columns]
 #pragma unroll
-          for (int j = 0; j < GGRP; ++j) {
-            const int col = 4 * (GGRP * g + j) + lj;
-            if (col < p.CZp) hz[(long)(16 * ar + srow) * p.CZp + col] = h[0][j] + h[1][j];
+          for (int i = 0; i < 4; ++i) { xb[(4 * i + lk) * 16 + lr] = D0[i]; xb[(16 + 4 * i + lk) * 16 + lr] = D1[i]; }   // D register i: row 4 i + (l >> 4), column l & 15
+          __syncthreads();
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) {                  // partials in column order: (wc, half) = (0,0), (0,1), (1,0), (1,1)
+            const double* src = lds + (2 * wr + (w4 >> 1) + 4 * (w4 & 1)) * 1280 + xpar * 512 + rrow * 16 + rcol;
+            s0 += src[0]; s1 += src[1];
           }
+          if (16 * g + rcol < p.CZp) {
+            double* hz = p.HZp + ((long)mt * p.Np + n0 + wrow0 + 32 * pr + rrow) * p.CZp + 16 * g + rcol;
+            hz[0] = s0; hz[1] = s1;
+          }
+          xpar ^= 1;
         }
       }
     }
-    __syncthreads();   // the slabs live in the staging buffers the next tile's DMA overwrites
+    __syncthreads();   // the wave areas live in the staging buffers the next tile's DMA overwrites
   }
 }
 
@@ -1257,31 +1202,46 @@ __global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict
 // per-point finish (general mode): HZ = sum of partials; grad_X_mu, grad_X_S, and the per-point part of grad_alpha
 struct PtArgs {
   const double* HZp; int nparts; long N, Np; int Q, CZp; const double* mu; const double* S; const double* alpha;
-  double* gmu; double* gS; double* gapart; int regimeA;
+  double* gmu; double* gS; double* gapart; int regimeA, pb;
 };
+// points per pass (their HZ rows are contiguous in every partial array, so the part sums are flat coalesced reads); LDS: pb (CZp + Q) + Q doubles
+static int point_pb(int CZp, int Q) { return std::max(1, std::min(32, (7000 - Q) / (CZp + Q))); }
 __global__ void __launch_bounds__(256) point_kernel(PtArgs a) {
-  extern __shared__ double red[];   // [256][Q] would be too big; accumulate per thread then reduce per q
-  for (int q = 0; q < a.Q; ++q) {
-    double ga = 0.0;
-    for (long n = blockIdx.x * 256L + threadIdx.x; n < a.N; n += (long)gridDim.x * 256L) {
-      double h = 0.0, hz = 0.0, hz2 = 0.0;
-      for (int i = 0; i < a.nparts; ++i) {
-        const double* row = a.HZp + ((long)i * a.Np + n) * a.CZp;
-        h += row[0]; hz += row[1 + q]; hz2 += row[1 + a.Q + q];
-      }
-      const double m = a.mu[n * a.Q + q], s = a.S[n * a.Q + q], al = a.alpha[q];
-      const double d1 = al * s + 1.0, u = al / d1;
-      const double quad = m * m * h - 2.0 * m * hz + hz2;
-      ga += -0.5 * (quad / (d1 * d1) + (s / d1) * h);
-      a.gmu[n * a.Q + q] = -m - u * (m * h - hz);
-      if (!a.regimeA) a.gS[n * a.Q + q] = -0.5 * (1.0 - 1.0 / s) + 0.5 * u * u * quad - 0.5 * u * h;
+  extern __shared__ double sm[];      // [pb][CZp] summed HZ rows | [pb][Q] grad_alpha contributions | [Q] this block's column sums (points in order)
+  double* hz = sm;
+  double* contrib = sm + a.pb * a.CZp;
+  double* gacc = contrib + a.pb * a.Q;
+  const int t = threadIdx.x;
+  for (int q = t; q < a.Q; q += 256) gacc[q] = 0.0;   // each column is only ever touched by the same thread
+  const long nchunks = (a.N + a.pb - 1) / a.pb;
+  for (long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const long n0 = ch * a.pb;
+    const int np = (int)min((long)a.pb, a.N - n0);
+    for (int e = t; e < np * a.CZp; e += 256) {
+      double s = 0.0;
+      for (int i = 0; i < a.nparts; ++i) s += a.HZp[((long)i * a.Np + n0) * a.CZp + e];
+      hz[e] = s;
     }
-    red[threadIdx.x] = ga;
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) a.gapart[(long)blockIdx.x * a.Q + q] = red[0];
+    for (int e = t; e < np * a.Q; e += 256) {
+      const int pi = e / a.Q, q = e - pi * a.Q;
+      const double* row = hz + pi * a.CZp;
+      const double h = row[0], hzq = row[1 + q], hz2 = row[1 + a.Q + q];
+      const double m = a.mu[n0 * a.Q + e], s = a.S[n0 * a.Q + e], al = a.alpha[q];
+      const double d1 = al * s + 1.0, u = al / d1;
+      const double quad = m * m * h - 2.0 * m * hzq + hz2;
+      contrib[e] = -0.5 * (quad / (d1 * d1) + (s / d1) * h);
+      a.gmu[n0 * a.Q + e] = -m - u * (m * h - hzq);
+      if (!a.regimeA) a.gS[n0 * a.Q + e] = -0.5 * (1.0 - 1.0 / s) + 0.5 * u * u * quad - 0.5 * u * h;
+    }
     __syncthreads();
+    for (int q = t; q < a.Q; q += 256) {
+      double ga = gacc[q];
+      for (int pi = 0; pi < np; ++pi) ga += contrib[pi * a.Q + q];
+      gacc[q] = ga;
+    }
   }
+  for (int q = t; q < a.Q; q += 256) a.gapart[(long)blockIdx.x * a.Q + q] = gacc[q];
 }
 
 __global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, int lda, const double* __restrict__ b, int rows_b, int ldb, int Q,
@@ -1313,6 +1273,7 @@ int run_phase2(gp_ctx* c) {
   p.S = S;
   p.kbeg = c->regime_A ? 0 : c->Mp / KC;
   p.kend = (c->Mp + (int)round_up(c->D, KC)) / KC;   // chunks beyond the last real Y column are all zero
+  p.klast = ((c->D - 1) % KC) / 4 + 1;
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
   const int nrb = (c->Q + 1 + 3) / 4;                // fast path: feature columns [mu (Q) | 1] in groups of four
   int hparts = 0;                                    // row-sum partial arrays the fast kernels leave in HZp
@@ -1347,10 +1308,11 @@ int run_phase2(gp_ctx* c) {
   GP_HIP(c, hipGetLastError());
   if (ppath) {
     PtArgs a;
-    a.HZp = c->HZp; a.nparts = 4 * p.MT;        // p2_gen8_kernel: one partial array per 32 inducing columns
+    a.HZp = c->HZp; a.nparts = p.MT;            // p2_gen8_kernel: one partial array per 128 inducing columns
     a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CZp = c->CZp; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
     a.gmu = c->gXmu; a.gS = c->gXs; a.gapart = c->gapart; a.regimeA = c->regime_A ? 1 : 0;
-    hipLaunchKernelGGL(point_kernel, dim3(c->ga_blocks), dim3(256), 256 * sizeof(double), c->stream, a);
+    a.pb = point_pb(c->CZp, c->Q);
+    hipLaunchKernelGGL(point_kernel, dim3(c->ga_blocks), dim3(256), (size_t)(a.pb * (c->CZp + c->Q) + c->Q) * sizeof(double), c->stream, a);
     GP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, c->gapart, c->ga_blocks, c->Q, c->Q, ga);
   } else {

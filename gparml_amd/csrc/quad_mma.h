@@ -7,8 +7,9 @@ namespace gp {
 // a double moved across lanes by a DPP control (quad_perm 0..0xFF, row_ror:n = 0x120 + n): two 32-bit DPP moves
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  // mov_dpp (no "old" operand): with update_dpp(0, ...) every move was preceded by a v_mov_b32 0 of its destination
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <int QP> __device__ __forceinline__ double quad_xchg(double v) { return dpp_move<QP>(v); }
@@ -23,18 +24,45 @@ template <int N> __device__ __forceinline__ double row_ror(double v) { return dp
 //   3. the four blocks are added with rotations by 8 and 4 lanes inside each row of 16 lanes.
 template <int NQ>
 __device__ __forceinline__ void wave_rows_times_features(const double (&T)[4], const double (&ZB)[4][NQ], double (&acc)[NQ]) {
-  const int lane = threadIdx.x & 63;
-  const bool p0 = (lane & 1) == 0, p1 = (lane & 2) == 0;
-  // the cross-lane moves are executed by ALL lanes before the selects: inside `cond ? a : move(b)` the move would run under
-  // the condition's exec mask and read its source lanes -- exactly the disabled ones -- as zero
-  const double x0 = quad_xchg<0xB1>(T[0]), x1 = quad_xchg<0xB1>(T[1]), x2 = quad_xchg<0xB1>(T[2]), x3 = quad_xchg<0xB1>(T[3]);
-  const double A0 = p0 ? T[0] : x1, A1 = p0 ? x0 : T[1], A2 = p0 ? T[2] : x3, A3 = p0 ? x2 : T[3];
-  const double y0 = quad_xchg<0x4E>(A0), y1 = quad_xchg<0x4E>(A1), y2 = quad_xchg<0x4E>(A2), y3 = quad_xchg<0x4E>(A3);
+  // Each of the two butterfly stages is a select between a lane's own value and its quad neighbour's: v_cndmask_b32 takes a DPP source, so
+  // move + select are ONE instruction per 32-bit half (16 for the whole transpose; as separate v_mov_b32_dpp + v_cndmask_b32 hipcc
+  // emitted 32, and another 28 v_mov_b32 0 for update_dpp's "old" operand).  D = vcc ? src1 : dpp(src0); vcc = lane parity masks.
+  // All 64 lanes must be active.  The leading s_nop covers the VALU-write -> DPP-read hazard the compiler cannot see into.
+  int t[4][2], a[4][2], o[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { t[i][0] = __double2loint(T[i]); t[i][1] = __double2hiint(T[i]); }
+  asm volatile(
+      "s_nop 1\n\t"
+      "s_mov_b64 vcc, %[m0]\n\t"
+      "v_cndmask_b32_dpp %[a0l], %[t1l], %[t0l], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a0h], %[t1h], %[t0h], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a2l], %[t3l], %[t2l], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a2h], %[t3h], %[t2h], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_not_b64 vcc, vcc\n\t"
+      "v_cndmask_b32_dpp %[a1l], %[t0l], %[t1l], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a1h], %[t0h], %[t1h], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a3l], %[t2l], %[t3l], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a3h], %[t2h], %[t3h], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[m1]\n\t"
+      "v_cndmask_b32_dpp %[o0l], %[a2l], %[a0l], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[o0h], %[a2h], %[a0h], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[o1l], %[a3l], %[a1l], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[o1h], %[a3h], %[a1h], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_not_b64 vcc, vcc\n\t"
+      "v_cndmask_b32_dpp %[o2l], %[a0l], %[a2l], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[o2h], %[a0h], %[a2h], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[o3l], %[a1l], %[a3l], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[o3h], %[a1h], %[a3h], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : [a0l] "=&v"(a[0][0]), [a0h] "=&v"(a[0][1]), [a1l] "=&v"(a[1][0]), [a1h] "=&v"(a[1][1]), [a2l] "=&v"(a[2][0]), [a2h] "=&v"(a[2][1]),
+        [a3l] "=&v"(a[3][0]), [a3h] "=&v"(a[3][1]), [o0l] "=&v"(o[0][0]), [o0h] "=&v"(o[0][1]), [o1l] "=&v"(o[1][0]), [o1h] "=&v"(o[1][1]),
+        [o2l] "=&v"(o[2][0]), [o2h] "=&v"(o[2][1]), [o3l] "=&v"(o[3][0]), [o3h] "=&v"(o[3][1])
+      : [t0l] "v"(t[0][0]), [t0h] "v"(t[0][1]), [t1l] "v"(t[1][0]), [t1h] "v"(t[1][1]), [t2l] "v"(t[2][0]), [t2h] "v"(t[2][1]),
+        [t3l] "v"(t[3][0]), [t3h] "v"(t[3][1]), [m0] "s"(0x5555555555555555ull), [m1] "s"(0x3333333333333333ull)
+      : "vcc", "scc");
   double At[4];
-  At[0] = p1 ? A0 : y2;
-  At[1] = p1 ? A1 : y3;
-  At[2] = p1 ? y0 : A2;
-  At[3] = p1 ? y1 : A3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) At[i] = __hiloint2double(o[i][1], o[i][0]);
 #pragma unroll
   for (int qq = 0; qq < NQ; ++qq) acc[qq] = 0.0;
 #pragma unroll

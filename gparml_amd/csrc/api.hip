@@ -114,7 +114,7 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   A(&c->Kaug, (size_t)Np * c->LDK);
   A(&c->Xmu, (size_t)N_s * Q); A(&c->Xs, (size_t)N_s * Q); A(&c->dir, (size_t)2 * N_s * Q);
   A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->U, (size_t)Np * Q); A(&c->PU, (size_t)Np * (2 * std::max(psi1_qp(Q), 2) + 2)); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
-  A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp);
+  A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp + 8);   // + 8: p2_gen8_kernel stages feature columns in groups of eight
   A(&c->stats, (size_t)Mp * Mp + Mp * Dp + SC_COUNT);
   A(&c->grads, (size_t)M * Q + Q);
   // phase-1 tile table: Psi2 upper tiles first, then the C tiles

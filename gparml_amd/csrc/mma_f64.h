@@ -48,6 +48,10 @@ enum Layout : int {
 __device__ __forceinline__ void mfma444_acc(double& c, double a, double b) {
   asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// first MFMA of an accumulation: C = 0 as an inline constant (no zeroing moves; "&": the result may not share a register with an operand)
+__device__ __forceinline__ void mfma444_zero(double& c, double a, double b) {
+  asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
 // wait states between the last in-flight MFMA and a VALU/VMEM read of an accumulator (4-pass DGEMM result).  The s_nop is
 // tied to one accumulator only; every OTHER accumulator that is read afterwards must pass acc_fence (an empty asm with the
 // register as an in/out operand, placed after the s_nop: volatile asms keep their order), otherwise the scheduler may

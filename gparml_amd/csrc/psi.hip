@@ -2,6 +2,7 @@
 // C = Psi1^T Y, KL), phase-2 gradient sums.  Reference: kernel_exp.py:13-148, partial_terms.py:38-87, 162-431,
 // local_MapReduce.py:183-248, 310-363.
 #include "gp_common.h"
+#include <vector>
 #include "fexp.h"
 #include <algorithm>
 #include <cstdlib>
@@ -549,6 +550,7 @@ struct P2Args {
   double* Rpart; double* HZp;
   int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend, klast; long Np;   // klast: k-steps (of 4) of the final chunk that hold real Y columns
   double* gapart;   // eight-wave fast kernel: [blocks * 8][4 NRB] per-wave partials of grad_alpha's mu^2 term
+  long long* dbg;   // timing build (GPARML_GEN8_TIMING): [blocks][8 waves][8 sections] s_memtime totals
 };
 
 constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
@@ -896,9 +898,10 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
 //   n-contraction  R[m][c]  += sum_n W[n][m] Xa[n][c]      straight from the registers: the accumulator layout IS the B operand of the
 //                  four-block MFMA, the blocks' partial sums are added through LDS (no transposed copy of W)
 //   m-contraction  HZ[n][c]  = sum_m W[n][m] Zaug[m][c]    W through a per-wave LDS slab pair (32 rows), read back transposed as the A
-//                  operand of v_mfma_f64_16x16x4; the four 32-column partials of a row are exchanged through LDS and added in column
-//                  order, so HZp holds one partial array per 128-column tile
-// 125-128 VGPRs, no scratch; configs[2] shape with free embeddings (1e5 points): 918 -> 403 us, point_kernel 241 -> 68 us.
+//                  operand; B = the Zaug rows of the wave's 32 columns, eight features at a time, staged by LDS-DMA one group ahead; the four
+//                  32-column partials of a row are exchanged through LDS and added in column order, so HZp holds one partial array per
+//                  128-column tile
+// 127 VGPRs, no scratch; configs[2] shape with free embeddings: 8.19 -> 3.66 ms per 1e6 points (918 -> 403 us per 1e5), point_kernel 2.4 -> 0.21 ms.
 constexpr int GSLD = 34;     // slab row stride (doubles): 16 x 32 values per wave
 template <bool PPATH>
 __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
@@ -916,6 +919,12 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
   const unsigned lds_base = lds_byte_addr(lds);
   // per wave a private 1280-double area: [0, 512) Psi1 slab A | [512, 1056) the W slab, which doubles as Psi1 slab B while W is being formed
   double* const area = lds + wave * 1280;
+#ifdef GPARML_GEN8_TIMING
+  long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define G8SEC(k) { const long long tn_ = __builtin_amdgcn_s_memtime(); tsec[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define G8SEC(k)
+#endif
   double* const slab = area + 512;
   auto chunk_dma = [&](double* buf, const double* a, const double* b) {
     int ld_ = lane;
@@ -944,9 +953,11 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
       for (int j = 0; j < 8; ++j) acc[ar][j] = 0.0;
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);                  // asm-defined zeros: no rematerialised v_mov in front of an asm MFMA
+    G8SEC(7)
     chunk_dma(lds, Ab, Bb);
     dma_wait();
     __syncthreads();
+    G8SEC(0)
     for (int c = 0; c < nc; ++c) {
       const int cur = c & 1;
       auto issue_next = [&]() { if (c + 1 < nc) chunk_dma(lds + (cur ^ 1) * 4608, Ab + (long)(c + 1) * KC, Bb + (long)(c + 1) * KC * p.Mp); };
@@ -975,6 +986,7 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
     mfma_drain(acc[3][7]);
 #pragma unroll
     for (int ar = 0; ar < 4; ++ar) acc_fence8(acc[ar]);
+    G8SEC(1)
     // ---- epilogue: the staging buffers are free.  Lane coordinates from an opaque copy (not held across the k-loop).
     int le = lane;
     asm volatile("" : "+v"(le));
@@ -1012,6 +1024,7 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
         }
       }
     }
+    G8SEC(2)
 #ifdef GPARML_GEN8_ABLATE   // timing experiments only (results wrong): bit 0 = no m-contraction, bit 1 = no n-contraction, bit 2 = no Psi1 product
     if (p.MT < 0) {
 #pragma unroll
@@ -1035,66 +1048,85 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
       const int nqx = p.CXp / 4, bsel = (le >> 2) & 3;
       const int ro = (8 * bsel + lj) * p.CXp + lk;
       const bool first = (nt == t0);
-      // (two quads in flight -- one in the MFMA pipe while the other's partials go through LDS -- needs 16 more VGPRs than there are: the
-      // compiler spilled seven accumulators; the loads below are issued a quad ahead instead)
-      double x[4], xn[4];
+      // A wave issues in order, so whatever is to run under a quad's 32 MFMAs must be REQUESTED before them: quad q - 1's old R values and
+      // quad q + 1's feature rows are issued first, the MFMAs of quad q follow, and quad q - 1's partial reads, sums and stores come behind them.  (Two quads' accumulators in flight would need 16 more VGPRs than there are: seven W registers spilled.)
+      double x[4], xn[4], d[8];
+      auto load_x = [&](double (&xv)[4], int q) {
 #pragma unroll
-      for (int ar = 0; ar < 4; ++ar) { x[ar] = xbase[xo + 16 * ar * p.CXp]; xn[ar] = 0.0; }
-      for (int q = 0; q < nqx; ++q) {
-        double d[8];
+        for (int ar = 0; ar < 4; ++ar) xv[ar] = xbase[xo + 16 * ar * p.CXp + 4 * q];
+      };
+      auto mfmas = [&]() {
+        asm volatile("s_nop 1");                           // x may come from a register copy: VALU write -> MFMA operand read needs two wait states
 #pragma unroll
-        for (int bc = 0; bc < 8; ++bc) d[bc] = 0.0;
-        acc_fence8(d);
-        // this lane finishes R[4 (2 bsel + s) + lj][4 q + lk], s = 0, 1
-        double* dst = Rmine + (ro + 4 * q);
-        double o0 = 0.0, o1 = 0.0;
-        if (!first) { o0 = dst[0]; o1 = dst[4 * p.CXp]; }
-        if (q + 1 < nqx) {
+        for (int bc = 0; bc < 8; ++bc) mfma444_zero(d[bc], x[0], acc[0][bc]);
 #pragma unroll
-          for (int ar = 0; ar < 4; ++ar) xn[ar] = xbase[xo + 16 * ar * p.CXp + 4 * (q + 1)];
-        }
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar)
+        for (int ar = 1; ar < 4; ++ar)
 #pragma unroll
           for (int bc = 0; bc < 8; ++bc) mfma444_acc(d[bc], x[ar], acc[ar][bc]);
+      };
+      auto park = [&]() {                                  // the quad's block partials to LDS (the registers are free again once the writes are issued)
         mfma_drain(d[7]);
         acc_fence8(d);
 #pragma unroll
         for (int bc = 0; bc < 8; ++bc) area[bc * 66 + le] = d[bc];
-        double v0 = 0.0, v1 = 0.0;
+      };
+      load_x(x, 0);
+#pragma unroll
+      for (int ar = 0; ar < 4; ++ar) xn[ar] = 0.0;
+      if (nqx > 1) load_x(xn, 1);
+      mfmas();
+      park();
+      for (int q = 1; q <= nqx; ++q) {
+        // quad q - 1: this lane finishes R[4 (2 bsel + s) + lj][4 (q - 1) + lk], s = 0, 1
+        double* dst = Rmine + (ro + 4 * (q - 1));
+        double o0 = 0.0, o1 = 0.0;
+        if (!first) { o0 = dst[0]; o1 = dst[4 * p.CXp]; }
+        double r0[4], r1[4];                                // (the LDS reads would also fit under the MFMAs, but not in the register file)
+        if (q < nqx) {
+#pragma unroll
+          for (int ar = 0; ar < 4; ++ar) x[ar] = xn[ar];
+          if (q + 1 < nqx) load_x(xn, q + 1);
+          // the parked partials must be out of d before the MFMAs overwrite it: the ds_writes have read their data when they are issued
+          mfmas();
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          v0 += area[(2 * bsel) * 66 + 16 * lk + 4 * b + lj];
-          v1 += area[(2 * bsel + 1) * 66 + 16 * lk + 4 * b + lj];
+          r0[b] = area[(2 * bsel) * 66 + 16 * lk + 4 * b + lj];
+          r1[b] = area[(2 * bsel + 1) * 66 + 16 * lk + 4 * b + lj];
         }
-        dst[0] = o0 + v0;
-        dst[4 * p.CXp] = o1 + v1;
-#pragma unroll
-        for (int ar = 0; ar < 4; ++ar) x[ar] = xn[ar];
+        dst[0] = o0 + ((r0[0] + r0[1]) + (r0[2] + r0[3]));
+        dst[4 * p.CXp] = o1 + ((r1[0] + r1[1]) + (r1[2] + r1[3]));
+        if (q < nqx) park();
       }
     }
-    // ---- m-contraction: HZ[n][c] = sum_m W[n][m] Zaug[m][c].  W goes through the wave's LDS area 32 rows at a time (the transposed
-    // read is the A operand of v_mfma_f64_16x16x4: lane (row l & 15, k l >> 4)); B = Zaug rows, 16 feature columns per instruction with
-    // 64 distinct values (lane (k l >> 4, column l & 15)), shared by the two 16-row slabs.  Each wave contracts its own 32 columns; the four
-    // partials of a 64-row half-tile are exchanged through LDS and added in column order, so HZp holds ONE array per 128-column tile.
+    G8SEC(3)
+    // ---- m-contraction: HZ[n][c] = sum_m W[n][m] Zaug[m][c].  W goes through the wave's LDS area 32 rows at a time (the transposed read is
+    // the MFMA A operand: lane (row l & 15, k l >> 4)) and stays in 16 registers; B = Zaug rows of the wave's 32 columns, eight feature
+    // columns per group, staged in LDS by DMA one group ahead (read from global memory it would be one replicated 512-byte load per MFMA).
+    // Each wave contracts its own 32 columns; the four partials of a 32-row half are exchanged through LDS and added in column order, so HZp
+    // holds ONE array per 128-column tile.  (v_mfma_f64_16x16x4 with 64 distinct B values per load was tried: half rate, same kernel time.)
 #if defined(GPARML_GEN8_ABLATE) && (GPARML_GEN8_ABLATE & 1)
     if (p.MT < 0)
 #else
     if (PPATH)
 #endif
     {
-      typedef double v4d __attribute__((ext_vector_type(4)));
       int lm = lane;                                        // fresh lane coordinates: carried over from above they are spilled
       asm volatile("" : "+v"(lm));
       const int lr = lm & 15, lk = lm >> 4, lj = lm & 3, le = lm;
       const int srow = 4 * ((lm >> 2) & 3) + (lm >> 4);
-      const int ng = (p.CZp + 15) / 16;
-      const double* zbase = p.Zaug + ((long)mt * TILE + wcol0) * p.CZp + lk * p.CZp;
+      const int ng = (p.CZp + 7) / 8;                       // feature columns in groups of eight (two quads)
+      // LDS area of the wave once the slabs are in registers: [0, 512) the Zaug rows of the wave's 32 columns x 8 features, staged by
+      // LDS-DMA one group ahead (two buffers) | [512, 1024) exchange buffers [2][32 rows][8 features]
+      double* const zst = area;
+      double* const xbuf = area + 512;
+      const double* zsrc = p.Zaug + ((long)mt * TILE + wcol0 + (lm >> 2)) * p.CZp + 2 * (lm & 3);   // DMA i: rows 16 i + (lane >> 2), 16-byte piece lane & 3
+      auto stage = [&](int g, double* dst) {
+        glds16(zsrc + 8 * g, dst);
+        glds16(zsrc + 16 * p.CZp + 8 * g, dst + 128);
+      };
       const int wi = 2 * wc + half;
-      double bn[8];
-#pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) bn[k4] = zbase[4 * k4 * p.CZp + min(lr, p.CZp - 1)];
-      const int rrow = 8 * wi + (le >> 3), rcol = 2 * (le & 7);
+      const int rrow = 8 * wi + (le >> 3), rcol = le & 7;
       int xpar = 0;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
@@ -1108,42 +1140,51 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int k4 = 0; k4 < 8; ++k4) a[t][k4] = area[t * 544 + lr * GSLD + 4 * k4 + lk];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slabs are in registers: their LDS is free for the staged rows
+        acc_fence8(a[0]); acc_fence8(a[1]);
+        stage(0, zst);
         for (int g = 0; g < ng; ++g) {
-          double b[8];
-#pragma unroll
-          for (int k4 = 0; k4 < 8; ++k4) b[k4] = bn[k4];
-          {                                                 // the next group's rows (the other slab pair starts over at group 0) load under the MFMAs
-            const int gn = (g + 1 < ng) ? g + 1 : 0;
-            const int col = min(16 * gn + lr, p.CZp - 1);   // columns past CZp: results discarded
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) bn[k4] = zbase[4 * k4 * p.CZp + col];
+          dma_wait();                                       // group g's rows have landed (and the previous group's HZ stores retired)
+          if (g + 1 < ng) stage(g + 1, zst + ((g + 1) & 1) * 256);
+          const double* zb = zst + (g & 1) * 256 + lk * 8 + lj;
+          double h[2][2];
+          {
+            const double b0 = zb[0], b1 = zb[4];                    // Zaug[wcol0 + lk][8 g + lj], [... + 4]
+            mfma444_zero(h[0][0], a[0][0], b0);
+            mfma444_zero(h[1][0], a[1][0], b0);
+            mfma444_zero(h[0][1], a[0][0], b1);
+            mfma444_zero(h[1][1], a[1][0], b1);
           }
-          v4d D0 = {0.0, 0.0, 0.0, 0.0}, D1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int k4 = 0; k4 < 8; ++k4) {
-            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][k4], b[k4], D0, 0, 0, 0);
-            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][k4], b[k4], D1, 0, 0, 0);
+          for (int k4 = 1; k4 < 8; ++k4) {
+            const double b0 = zb[32 * k4], b1 = zb[32 * k4 + 4];   // Zaug[wcol0 + 4 k4 + lk][8 g + lj], [... + 4]
+            mfma444_acc(h[0][0], a[0][k4], b0);
+            mfma444_acc(h[1][0], a[1][k4], b0);
+            mfma444_acc(h[0][1], a[0][k4], b1);
+            mfma444_acc(h[1][1], a[1][k4], b1);
           }
-          double* xb = area + xpar * 512;                   // exchange buffer [32 rows][16 columns]
+          mfma_drain(h[1][1]);
+          acc_fence<2>(h[0]); acc_fence<2>(h[1]);
+          double* xb = xbuf + xpar * 256;                   // [32 rows][8 features]: this wave's partial over its 32 columns
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { xb[(4 * i + lk) * 16 + lr] = D0[i]; xb[(16 + 4 * i + lk) * 16 + lr] = D1[i]; }   // D register i: row 4 i + (l >> 4), column l & 15
+          for (int t = 0; t < 2; ++t) { xb[(16 * t + srow) * 8 + lj] = h[t][0]; xb[(16 * t + srow) * 8 + 4 + lj] = h[t][1]; }
           __syncthreads();
-          double s0 = 0.0, s1 = 0.0;
+          double s0 = 0.0;
 #pragma unroll
-          for (int w4 = 0; w4 < 4; ++w4) {                  // partials in column order: (wc, half) = (0,0), (0,1), (1,0), (1,1)
-            const double* src = lds + (2 * wr + (w4 >> 1) + 4 * (w4 & 1)) * 1280 + xpar * 512 + rrow * 16 + rcol;
-            s0 += src[0]; s1 += src[1];
-          }
-          if (16 * g + rcol < p.CZp) {
-            double* hz = p.HZp + ((long)mt * p.Np + n0 + wrow0 + 32 * pr + rrow) * p.CZp + 16 * g + rcol;
-            hz[0] = s0; hz[1] = s1;
-          }
+          for (int w4 = 0; w4 < 4; ++w4)                    // partials in column order: (wc, half) = (0,0), (0,1), (1,0), (1,1)
+            s0 += lds[(2 * wr + (w4 >> 1) + 4 * (w4 & 1)) * 1280 + 512 + xpar * 256 + rrow * 8 + rcol];
+          if (8 * g + rcol < p.CZp) p.HZp[((long)mt * p.Np + n0 + wrow0 + 32 * pr + rrow) * p.CZp + 8 * g + rcol] = s0;
           xpar ^= 1;
         }
       }
     }
+    G8SEC(4)
     __syncthreads();   // the wave areas live in the staging buffers the next tile's DMA overwrites
+    G8SEC(5)
   }
+#ifdef GPARML_GEN8_TIMING
+  if (p.dbg && lane == 0) for (int k = 0; k < 8; ++k) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + k] = tsec[k];
+#endif
 }
 
 // grad_alpha's mu^2 term from the row sums: out[block][q] = -1/2 sum_{n in block} (sum_p H[p][n]) mu_nq^2   (fixed tree)
@@ -1278,7 +1319,25 @@ int run_phase2(gp_ctx* c) {
   const int nrb = (c->Q + 1 + 3) / 4;                // fast path: feature columns [mu (Q) | 1] in groups of four
   int hparts = 0;                                    // row-sum partial arrays the fast kernels leave in HZp
   (void)hipEventRecord(c->ev[12], c->stream);
+  p.dbg = nullptr;
+#ifdef GPARML_GEN8_TIMING
+  static long long* g8dbg = nullptr;
+  if (!g8dbg) GP_HIP(c, hipMalloc((void**)&g8dbg, (size_t)65536 * 64 * sizeof(long long)));
+  p.dbg = g8dbg;
+#endif
   if (ppath) hipLaunchKernelGGL((p2_gen8_kernel<true>), dim3(blocks), dim3(512), 0, c->stream, p);
+#ifdef GPARML_GEN8_TIMING
+  if (ppath) {
+    std::vector<long long> h((size_t)blocks * 64);
+    GP_HIP(c, hipMemcpy(h.data(), g8dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    const char* names[8] = {"first chunk", "k-loop", "Psi1 product", "n-contraction", "m-contraction", "tile barrier", "-", "tile setup"};
+    for (int blk : {0, blocks / 2}) for (int wv : {0, 5}) {
+      fprintf(stderr, "[gen8 timing] block %d wave %d, %d tiles (s_memtime ticks, 100 MHz):", blk, wv, p.tps);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%lld", names[k], h[((size_t)blk * 8 + wv) * 8 + k]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   else if (nrb <= 3) {
     p.gapart = c->hgpart;
     GP_HIP(c, hipMemsetAsync(c->hgpart, 0, (size_t)blocks * 8 * 4 * nrb * sizeof(double), c->stream));   // blocks past the last slice exit early

@@ -74,10 +74,6 @@ __device__ __forceinline__ double mul_asm(double a, double b) {   // ordered wit
   return r;
 }
 
-// first MFMA of an accumulation: C = 0 as an inline constant (no zeroing moves; "&": the result may not share a register with an operand)
-__device__ __forceinline__ void mfma444_zero(double& c, double a, double b) {
-  asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-}
 
 // LDS image of the current point's tile for the two contractions: element (row, col) of T at tx[col * TXS + (row ^ 16 (col & 1))].
 // With TXS = 66 the column side's operand reads (16 columns x rows 4 s + {0, 1} per 32-lane group) are conflict-free and the row side's

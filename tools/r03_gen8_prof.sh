@@ -8,10 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 prof() { tag=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats -d $O/$tag -o $tag --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > $O/$tag.log 2>&1; }
 prof c4 --N 20000 --D 1000 --M 1024 --Q 50 --regime B
 prof c2B --N 100000 --D 100 --M 512 --Q 10 --regime B
+prof c2B_1e6 --N 1000000 --D 100 --M 512 --Q 10 --regime B
 python3 - <<PY
 import csv, glob
 out=[]
-for tag in ('c4','c2B'):
+for tag in ('c4','c2B','c2B_1e6'):
     out.append('== ' + tag)
     for f in glob.glob('$O/%s/*kernel_stats.csv' % tag):
         rows=list(csv.DictReader(open(f)))

@@ -96,7 +96,35 @@ __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict
     const bool diag = (i == k) && i < M;
     Kmm[idx] = v + (diag ? jitK : 0.0);
     Keep[idx] = v;
-    A[idx] = v + ((i < M && k < M) ? beta * Psi2[idx] : 0.0) + (diag ? jitA : 0.0);
+    A[idx] = ((i < M && k < M) ? fma(beta, Psi2[idx], v) : v) + (diag ? jitA : 0.0);   // the same expression as in solve_residual_kernel
+  }
+}
+
+// One step of iterative refinement for E = A^-1 C (A = Kmm + beta Psi2, cond(A) ~ 1e10 at the benchmark's size): R = C - A E with the
+// products and the sum carried in double-double (error-free product by FMA, two-sum accumulation), rounded to double at the end; the caller
+// then adds P R.  A is rebuilt from Kmm and Psi2 exactly as build_kmm_kernel rounds it (the factorisation overwrote its copy).  One
+// workgroup per row m: A[m][k] is wave-uniform, E[k][:] a coalesced row.  With float64 residuals the step is worthless (the residual IS the
+// rounding error); with this one the error of grad_Z against an 80-bit evaluation drops from 1.3e-5 to 7e-6 at N = 1e6.
+__global__ void __launch_bounds__(128) solve_residual_kernel(const double* __restrict__ Keep, const double* __restrict__ Psi2, double beta, double jitA,
+                                                             const double* __restrict__ C, const double* __restrict__ E, int M, int Mp, int Dp,
+                                                             double* __restrict__ R) {
+#pragma clang fp contract(off)   // the error-free transformations below must not be fused (hi + a e as one FMA breaks the two-sum)
+  const int m = blockIdx.x;
+  const double* krow = Keep + (long)m * Mp;
+  const double* prow = Psi2 + (long)m * Mp;
+  for (int d = threadIdx.x; d < Dp; d += 128) {
+    double hi = 0.0, lo = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < M; ++k) {
+      const double a = fma(beta, prow[k], krow[k]) + (k == m ? jitA : 0.0);
+      const double e = E[(long)k * Dp + d];
+      const double pr = a * e, pe = fma(a, e, -pr);           // a e = pr + pe exactly
+      const double t = hi + pr, bb = t - hi;                   // two-sum
+      lo += ((hi - (t - bb)) + (pr - bb)) + pe;
+      hi = t;
+    }
+    const double c0 = C[(long)m * Dp + d];
+    R[(long)m * Dp + d] = (c0 - hi) - lo;
   }
 }
 
@@ -298,6 +326,17 @@ int run_global_step(gp_ctx* c) {
   if (two) { GP_HIP(c, hipEventRecord(c->gev[0], st)); GP_HIP(c, hipStreamWaitEvent(s2, c->gev[0], 0)); }
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
+  // one refinement step of E with a double-double residual (PsiE is free until the next product); GPARML_REFINE_E=0 turns it off
+  static const bool refine_E = [] { const char* e = getenv("GPARML_REFINE_E"); return !(e && e[0] == '0'); }();
+  if (refine_E) {
+    hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(128), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
+                       c->PsiE);
+    GP_HIP(c, hipGetLastError());
+    if (M < Mp) GP_HIP(c, hipMemsetAsync(c->PsiE + (long)M * Dp, 0, (size_t)(Mp - M) * Dp * sizeof(double), st));
+    g.A = P; g.lda = Mp; g.B = c->PsiE; g.ldb = Dp; g.C = c->E; g.ldc = Dp; g.beta = 1.0;
+    launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
+    g.beta = 0.0;
+  }
   g.A = Psi2; g.lda = Mp; g.B = c->E; g.ldb = Dp; g.C = c->PsiE; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG

@@ -11,9 +11,12 @@ the truth with the errors of the two float64 CPU arrangements:
 i.e. NO float64 evaluation of this bound certifies grad_Z to 1e-5 at this conditioning: with the long-double partials rounded to
 double the float64 phase 2 reproduces grad_Z to 1.9e-10, so the whole error is the M x M global step, and even a long-double
 global step on double-rounded statistics is left with 6e-9 on dF/dPsi2, which grad_Z (a ~1000-fold amplification through the
-K_mm part) turns into ~1e-6..1e-5.  The device path is held to the reference's own distance from the truth:
+K_mm part) turns into ~1e-6..1e-5.  The device's global step refines E = (K_mm + beta Psi2)^-1 Psi1^T Y once with a
+double-double residual (csrc/linalg.hip, solve_residual_kernel), which takes its grad_Z from 3.7e-5 / 1.3e-5 to 1.07e-5 / 7.5e-6 (N = 1e5 / 1e6).
+The device path is held to
 
-    err(GPU, truth) <= max(1e-5, err(float64 LU, truth))    per gradient block, relative to the block's largest magnitude
+    err(GPU, truth) <= max(1e-5, best float64 CPU arrangement's error)    per gradient block, relative to the block's largest magnitude
+    err(GPU, truth) <= 1e-5 on every block at the full size N = 1e6 (the headline configuration)
     |F_gpu - F_truth| <= 1e-9 |F_truth|
 """
 import os
@@ -84,4 +87,6 @@ def test_gpu_against_the_long_double_truth(N):
     rep = {k: (_err(out[k], z['truth_' + k]), float(z['err_lu_' + k]), float(z['err_chol_' + k])) for k in BLOCKS}
     print('N=%d error vs truth (gpu, float64 LU, float64 Cholesky):' % N, {k: '%.2e %.2e %.2e' % v for k, v in rep.items()})
     for k in BLOCKS:
-        assert rep[k][0] <= max(1e-5, rep[k][1]), (k, rep[k])
+        assert rep[k][0] <= max(1e-5, min(rep[k][1], rep[k][2])), (k, rep[k])
+        if N == 1000000:
+            assert rep[k][0] <= 1e-5, (k, rep[k])

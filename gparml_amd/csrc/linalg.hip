@@ -104,10 +104,11 @@ __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict
 // products and the sum carried in double-double (error-free product by FMA, two-sum accumulation), rounded to double at the end; the caller
 // then adds P R.  A is rebuilt from Kmm and Psi2 exactly as build_kmm_kernel rounds it (the factorisation overwrote its copy).  One
 // workgroup per row m: A[m][k] is wave-uniform, E[k][:] a coalesced row.  With float64 residuals the step is worthless (the residual IS the
-// rounding error); with this one the error of grad_Z against an 80-bit evaluation drops from 1.3e-5 to 7e-6 at N = 1e6.
+// rounding error); with this one the error of grad_Z against an 80-bit evaluation drops from 1.3e-5 to 7.5e-6 at N = 1e6.
+// `identity`: C = I (the residual of an inverse: refining P = A^-1 the same way was measured -- no change in grad_Z, +0.17 ms -- and is not done).
 __global__ void __launch_bounds__(128) solve_residual_kernel(const double* __restrict__ Keep, const double* __restrict__ Psi2, double beta, double jitA,
                                                              const double* __restrict__ C, const double* __restrict__ E, int M, int Mp, int Dp,
-                                                             double* __restrict__ R) {
+                                                             double* __restrict__ R, int identity) {
 #pragma clang fp contract(off)   // the error-free transformations below must not be fused (hi + a e as one FMA breaks the two-sum)
   const int m = blockIdx.x;
   const double* krow = Keep + (long)m * Mp;
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(128) solve_residual_kernel(const double* __res
       lo += ((hi - (t - bb)) + (pr - bb)) + pe;
       hi = t;
     }
-    const double c0 = C[(long)m * Dp + d];
+    const double c0 = identity ? (d == m ? 1.0 : 0.0) : C[(long)m * Dp + d];
     R[(long)m * Dp + d] = (c0 - hi) - lo;
   }
 }
@@ -330,7 +331,7 @@ int run_global_step(gp_ctx* c) {
   static const bool refine_E = [] { const char* e = getenv("GPARML_REFINE_E"); return !(e && e[0] == '0'); }();
   if (refine_E) {
     hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(128), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
-                       c->PsiE);
+                       c->PsiE, 0);
     GP_HIP(c, hipGetLastError());
     if (M < Mp) GP_HIP(c, hipMemsetAsync(c->PsiE + (long)M * Dp, 0, (size_t)(Mp - M) * Dp * sizeof(double), st));
     g.A = P; g.lda = Mp; g.B = c->PsiE; g.ldb = Dp; g.C = c->E; g.ldc = Dp; g.beta = 1.0;

@@ -554,7 +554,6 @@ struct P2Args {
 };
 
 constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
-constexpr int GRP = 6;        // feature columns are processed 24 at a time (6 B registers)
 
 
 // Fast variants for the fixed-embedding regime (no per-point outputs), Q + 1 <= 4 * NRB <= 24.  Per-point features are
@@ -990,7 +989,7 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
     // ---- epilogue: the staging buffers are free.  Lane coordinates from an opaque copy (not held across the k-loop).
     int le = lane;
     asm volatile("" : "+v"(le));
-    const int lr = le & 15, lk = le >> 4, lj = le & 3;
+    const int lk = le >> 4, lj = le & 3;
     const int srow = 4 * ((le >> 2) & 3) + (le >> 4);
     // W = G o Psi1 in the accumulator layout (row 16 ar + srow, column 4 bc + lj of the wave's 64 x 32 block).  The wave's Psi1 block
     // arrives by LDS-DMA in four 16-row slabs, two in flight (register-staged loads of the 32 values do not fit next to the accumulators:

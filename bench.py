@@ -289,6 +289,8 @@ def main():
             res['config']['allreduce_ms'] = {k: round(v, 4) for k, v in coll.items()}
             res['config']['allreduce_ms']['total'] = round(sum(coll.values()), 4)
             res['config']['global_ms'] = round(kern['global_ms'], 4)
+        res['config']['global_step'] = ('float64 blocked Cholesky + inverses; E = (Kmm + beta Psi2)^-1 Psi1^T Y refined once with a double-double residual'
+                                        if os.environ.get('GPARML_REFINE_E', '1') != '0' else 'float64 blocked Cholesky + inverses (GPARML_REFINE_E=0)')
         if a.regime == 'A':
             # parity of THIS run's last evaluation against the extended-precision truth of the same workload (rank 0's shard alone:
             # only meaningful for one shard), and the conditioning it was obtained at

@@ -65,7 +65,7 @@ __device__ __forceinline__ double fexp_t(double x, const ExpTab& tb) {
   double r = fma(n, -0x1.62e42ff000000p-7, x);                   // ln2/64, upper 30 bits (n * hi is exact for |n| < 2^22)
   r = fma(n, 6.56392980106419468e-13, r);                       // -(ln2/64 - hi)
   const int ni = (int)n;
-  const int sel = (ni & 63) << 2;
+  const int sel = ni << 2;                                       // ds_bpermute takes the lane as (byte address / 4) mod 64: no mask needed
   const int lo = __builtin_amdgcn_ds_bpermute(sel, tb.lo), hi = __builtin_amdgcn_ds_bpermute(sel, tb.hi);
   double p = 1.0 / 120.0;
   p = fma(p, r, 1.0 / 24.0);

@@ -142,15 +142,22 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
   }
   const long per = (N + S - 1) / S;
   const long n0 = slice * per, n1 = min(N, n0 + per);
-  const double* l1 = LE + m1;
-  const double* l2 = LE + m2;
   const ExpTab xt = exp_tab_lane();
+  unsigned o1 = 8u * (unsigned)m1, o2 = 8u * (unsigned)m2;
   double acc0 = 0.0, acc1 = 0.0;
   long n = n0;
   for (; n + 4 <= n1; n += 4) {
     double e[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) e[u] = l1[(n + u) * Mp] + l2[(n + u) * Mp];
+    for (int u = 0; u < 4; ++u) {
+      // wave-uniform row base + 32-bit BYTE offsets of the lane: scalar-base addressing (global_load v, voff, s[base]), no per-lane 64-bit
+      // address arithmetic (two v_lshl_add_u64 per point before; an element index instead of a byte offset does not get it: its shift
+      // by 3 may not fit 32 bits as far as the compiler knows; the offsets pass through an empty asm, otherwise LE + offset is hoisted
+      // out of the loop as a per-lane 64-bit pointer again)
+      const char* row = reinterpret_cast<const char*>(LE + (n + u) * Mp);
+      asm volatile("" : "+v"(o1), "+v"(o2));
+      e[u] = *reinterpret_cast<const double*>(row + o1) + *reinterpret_cast<const double*>(row + o2);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const double* v = V2P + (n + u) * QT;      // wave-uniform
@@ -161,7 +168,8 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
     acc1 += fexp_t(e[1], xt) + fexp_t(e[3], xt);
   }
   for (; n < n1; ++n) {
-    double e = l1[n * Mp] + l2[n * Mp];
+    const char* row = reinterpret_cast<const char*>(LE + n * Mp);
+    double e = *reinterpret_cast<const double*>(row + o1) + *reinterpret_cast<const double*>(row + o2);
     const double* v = V2P + n * QT;
 #pragma unroll
     for (int q = 0; q < QT; ++q) e = fma(v[q], dz[q], e);

@@ -106,26 +106,46 @@ __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict
 // workgroup per row m: A[m][k] is wave-uniform, E[k][:] a coalesced row.  With float64 residuals the step is worthless (the residual IS the
 // rounding error); with this one the error of grad_Z against an 80-bit evaluation drops from 1.3e-5 to 7.5e-6 at N = 1e6.
 // `identity`: C = I (the residual of an inverse: refining P = A^-1 the same way was measured -- no change in grad_Z, +0.17 ms -- and is not done).
-__global__ void __launch_bounds__(128) solve_residual_kernel(const double* __restrict__ Keep, const double* __restrict__ Psi2, double beta, double jitA,
+__global__ void __launch_bounds__(512) solve_residual_kernel(const double* __restrict__ Keep, const double* __restrict__ Psi2, double beta, double jitA,
                                                              const double* __restrict__ C, const double* __restrict__ E, int M, int Mp, int Dp,
                                                              double* __restrict__ R, int identity) {
 #pragma clang fp contract(off)   // the error-free transformations below must not be fused (hi + a e as one FMA breaks the two-sum)
-  const int m = blockIdx.x;
+  // 128 columns x 4 quarters of the contraction range per workgroup: four waves per SIMD hide the latency of the E loads behind each other's
+  // two-sum chains (one thread per column, 1024 waves in all: 44 us at M = 512).  The quarter is wave-uniform (readfirstlane), so A[m][k] stays a
+  // scalar load.  The four double-double partials are added in order by the first quarter's thread.
+  __shared__ double ph[3][128], pl[3][128];
+  const int m = blockIdx.x, dl = threadIdx.x & 127, kq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
   const double* krow = Keep + (long)m * Mp;
   const double* prow = Psi2 + (long)m * Mp;
-  for (int d = threadIdx.x; d < Dp; d += 128) {
+  const int kper = (M + 3) / 4, k0 = kq * kper, k1 = min(M, k0 + kper);
+  for (int d0 = 0; d0 < Dp; d0 += 128) {
+    const int d = d0 + dl;
     double hi = 0.0, lo = 0.0;
+    if (d < Dp) {
 #pragma unroll 8
-    for (int k = 0; k < M; ++k) {
-      const double a = fma(beta, prow[k], krow[k]) + (k == m ? jitA : 0.0);
-      const double e = E[(long)k * Dp + d];
-      const double pr = a * e, pe = fma(a, e, -pr);           // a e = pr + pe exactly
-      const double t = hi + pr, bb = t - hi;                   // two-sum
-      lo += ((hi - (t - bb)) + (pr - bb)) + pe;
-      hi = t;
+      for (int k = k0; k < k1; ++k) {
+        const double a = fma(beta, prow[k], krow[k]) + (k == m ? jitA : 0.0);
+        const double e = E[(long)k * Dp + d];
+        const double pr = a * e, pe = fma(a, e, -pr);           // a e = pr + pe exactly
+        const double t = hi + pr, bb = t - hi;                   // two-sum
+        lo += ((hi - (t - bb)) + (pr - bb)) + pe;
+        hi = t;
+      }
     }
-    const double c0 = identity ? (d == m ? 1.0 : 0.0) : C[(long)m * Dp + d];
-    R[(long)m * Dp + d] = (c0 - hi) - lo;
+    if (kq > 0) { ph[kq - 1][dl] = hi; pl[kq - 1][dl] = lo; }
+    __syncthreads();
+    if (kq == 0 && d < Dp) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double x = ph[j][dl];
+        const double t = hi + x, bb = t - hi;
+        lo += ((hi - (t - bb)) + (x - bb)) + pl[j][dl];
+        hi = t;
+      }
+      const double c0 = identity ? (d == m ? 1.0 : 0.0) : C[(long)m * Dp + d];
+      R[(long)m * Dp + d] = (c0 - hi) - lo;
+    }
+    __syncthreads();
   }
 }
 
@@ -330,7 +350,7 @@ int run_global_step(gp_ctx* c) {
   // one refinement step of E with a double-double residual (PsiE is free until the next product); GPARML_REFINE_E=0 turns it off
   static const bool refine_E = [] { const char* e = getenv("GPARML_REFINE_E"); return !(e && e[0] == '0'); }();
   if (refine_E) {
-    hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(128), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
+    hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(512), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
                        c->PsiE, 0);
     GP_HIP(c, hipGetLastError());
     if (M < Mp) GP_HIP(c, hipMemsetAsync(c->PsiE + (long)M * Dp, 0, (size_t)(Mp - M) * Dp * sizeof(double), st));

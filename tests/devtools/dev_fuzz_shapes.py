@@ -1,0 +1,50 @@
+"""Dev fuzz (GPU box): random small shapes in both regimes against the oracle -- looks for crashes / wrong answers at odd sizes
+(N below a tile, M = 1, M > N, Q up to 63, D up to 300).  r03: 70 shapes, 68 within 1e-5 (most 1e-12), two flagged with cond 2e14 / 9e11.  Usage: dev_fuzz_shapes.py [count] [seed]"""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for it in range(count):
+    regime = 'AB'[rs.randint(2)]
+    Q = int(rs.choice([1, 2, 3, 5, 8, 10, 11, 12, 16, 17, 23, 24, 25, 31, 40, 50, 51, 52, 60, 63]))
+    M = int(rs.choice([1, 2, 7, 16, 33, 64, 65, 100, 128, 129, 200, 257, 300]))
+    N = int(rs.choice([1, 2, 17, 63, 64, 127, 128, 129, 300, 777, 1500]))
+    D = int(rs.choice([1, 2, 3, 4, 5, 15, 16, 17, 33, 100, 104, 105, 130, 300]))
+    if regime == 'B' and Q > 24 and M > 130:      # keep the oracle's pairwise tensor small
+        M = 64
+    d = Fz.synthetic_shard(N, D, min(M, N), Q, regime=regime, seed=100 + it, zseed=200 + it, alpha_value=min(0.5, 2.0 / Q))
+    if M > N:
+        d['Z'] = 1.5 * np.random.RandomState(300 + it).randn(M, Q)      # more inducing points than data points
+    try:
+        ref = Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=4, pairs='gemm')
+    except np.linalg.LinAlgError:
+        print('skip (oracle: not PD)', (N, D, M, Q, regime), flush=True)
+        continue
+    eng = ShardEngine(N, D, M, Q)
+    try:
+        eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+        eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        out = eng.evaluate(True)
+        errs = {k: float(np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) / max(np.max(np.abs(ref[k])), 1e-300))
+                for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu') + (('grad_X_S',) if regime == 'B' else ())}
+        errs['F'] = abs(out['F'] - ref['F']) / abs(ref['F'])
+        worst = max(errs.values())
+        flag = ''
+        if worst >= 1e-5:
+            dz = d['Z'][:, None, :] - d['Z'][None, :, :]
+            Kmm = d['sf2'] * np.exp(-0.5 * np.sum(np.asarray(d['alpha'])[None, None, :] * dz * dz, axis=2))
+            cond = np.linalg.cond(Kmm + d['beta'] * ref['stats']['sum_exp_K_mi_K_im'])
+            flag = '   <<<<<< %s, cond(Kmm + beta Psi2) = %.1e%s' % (max(errs, key=errs.get), cond, ' (float64 carries no digits there)' if cond > 1e11 else '')
+            if cond <= 1e11: bad += 1
+        print((N, D, M, Q, regime), 'worst %.1e%s' % (worst, flag), flush=True)
+    except Exception as e:
+        bad += 1
+        print((N, D, M, Q, regime), 'EXCEPTION', type(e).__name__, str(e)[:200], flush=True)
+    finally:
+        eng.close()
+print('FUZZ done, flagged', bad)

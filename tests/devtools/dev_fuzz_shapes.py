@@ -15,13 +15,18 @@ for it in range(count):
     M = int(rs.choice([1, 2, 7, 16, 33, 64, 65, 100, 128, 129, 200, 257, 300]))
     N = int(rs.choice([1, 2, 17, 63, 64, 127, 128, 129, 300, 777, 1500]))
     D = int(rs.choice([1, 2, 3, 4, 5, 15, 16, 17, 33, 100, 104, 105, 130, 300]))
-    if regime == 'B' and Q > 24 and M > 130:      # keep the oracle's pairwise tensor small
+    big = len(sys.argv) > 3 and sys.argv[3] == 'big'
+    if big:                                         # several row tiles / inducing tiles / slices
+        N = int(rs.choice([2000, 5000, 12000, 33000])); M = int(rs.choice([130, 257, 513, 700, 1025, 1100])); D = int(rs.choice([10, 100, 333, 1000]))
+        Q = int(rs.choice([2, 5, 10, 12, 16, 20, 24, 30, 50]))
+        if regime == 'B': N = min(N, 5000); M = min(M, 513 if Q <= 24 else 257)
+    elif regime == 'B' and Q > 24 and M > 130:      # keep the oracle's pairwise tensor small
         M = 64
-    d = Fz.synthetic_shard(N, D, min(M, N), Q, regime=regime, seed=100 + it, zseed=200 + it, alpha_value=min(0.5, 2.0 / Q))
+    d = Fz.synthetic_shard(N, D, min(M, N), Q, regime=regime, seed=100 + it, zseed=200 + it, alpha_value=(min(1.0, 6.0 / Q) if big else min(0.5, 2.0 / Q)))
     if M > N:
         d['Z'] = 1.5 * np.random.RandomState(300 + it).randn(M, Q)      # more inducing points than data points
     try:
-        ref = Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=4, pairs='gemm')
+        ref = Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=16 if big else 4, pairs='gemm')
     except np.linalg.LinAlgError:
         print('skip (oracle: not PD)', (N, D, M, Q, regime), flush=True)
         continue

@@ -1048,7 +1048,8 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
       const int ro = (8 * bsel + lj) * p.CXp + lk;
       const bool first = (nt == t0);
       // A wave issues in order, so whatever is to run under a quad's 32 MFMAs must be REQUESTED before them: quad q - 1's old R values and
-      // quad q + 1's feature rows are issued first, the MFMAs of quad q follow, and quad q - 1's partial reads, sums and stores come behind them.  (Two quads' accumulators in flight would need 16 more VGPRs than there are: seven W registers spilled.)
+      // quad q + 1's feature rows are issued first, the MFMAs of quad q follow, and quad q - 1's partial reads, sums and stores come behind them.
+      // (Two quads' accumulators in flight would need 16 more VGPRs than there are: seven W registers spilled.)
       double x[4], xn[4], d[8];
       auto load_x = [&](double (&xv)[4], int q) {
 #pragma unroll

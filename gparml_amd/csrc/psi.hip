@@ -810,7 +810,13 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
       static_for<0, KC / 4>([&](auto k4c) {
         constexpr int k4 = decltype(k4c)::value;
         if constexpr (k4 == 2) { if (half == 1) issue_next(); }
-        if (k4 > 0 && tail && k4 >= p.klast) return;   // k-steps past the last real Y column multiply zeros
+#ifdef GPARML_FAST8_KSKIP
+        // Skipping the k-steps that only multiply Y's zero padding (three of 156 at D = 100) is NOT done here: same kernel time (the last chunk of a
+        // tile waits for the epilogue's first DMA anyway), but FETCH_SIZE 11.55 -> 14.2 GB per launch, reproducibly (tools/r03_traffic_ab.sh): the
+        // shortened last chunk lets the four m-tile workgroups of a slice drift apart and they stop finding each other's rows in L2.
+        // p2_gen8_kernel, whose k-loop at D = 100 is seven chunks, keeps the skip (-10 % of its loop).
+        if (k4 > 0 && tail && k4 >= p.klast) return;
+#endif
         const unsigned aA = sbase_b + 8u * (unsigned)ofs.a[k4];
         double a[4], b[8];
         a[0] = ds_read64<0>(aA); a[1] = ds_read64<2048>(aA); a[2] = ds_read64<4096>(aA); a[3] = ds_read64<6144>(aA);

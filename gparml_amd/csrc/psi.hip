@@ -178,7 +178,10 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       double2 v;
       v.x = (n < N && ok0) ? x0 : 0.0;
       v.y = (n < N && ok1) ? x1 : 0.0;
-      if (col < Mp) *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
+      // non-temporal (one global_store_dwordx4 ... nt per lane): the 4.1 GB of Psi1 is next read after the whole array has been written,
+      // so keeping it in L2 / MALL only evicts what the statistics kernels are about to use -- same-box A/B (three rounds): this kernel
+      // 0.912 -> 0.932 ms, but p1v2_kernel 5.860 -> 5.795 and p2_fast8_kernel 10.051 -> 9.995 ms: evaluation 17.457 -> 17.354 ms
+      if (col < Mp) { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
     }
     if (g + 1 < NG) {
 #pragma unroll

@@ -22,7 +22,7 @@ for tag in ('sq1','sq2','sq3'):
         agg=collections.OrderedDict()
         for r in csv.DictReader(open(f)):
             k=r['Kernel_Name'].split('(')[0][:44]
-            if 'psi2_' not in k: continue
+            if not any(x in k for x in ('psi2_', 'gen8', 'point_kernel')): continue
             agg.setdefault(k,collections.OrderedDict()).setdefault(r['Counter_Name'],[]).append(float(r['Counter_Value']))
         for k,v in agg.items():
             print('%-44s %s' % (k, ' '.join('%s=%.4g' % (c, sum(x)/len(x)) for c,x in v.items())))

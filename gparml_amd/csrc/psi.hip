@@ -1126,7 +1126,8 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
       const int srow = 4 * ((lm >> 2) & 3) + (lm >> 4);
       const int ng = (p.CZp + 7) / 8;                       // feature columns in groups of eight (two quads)
       // LDS area of the wave once the slabs are in registers: [0, 512) the Zaug rows of the wave's 32 columns x 8 features, staged by
-      // LDS-DMA one group ahead (two buffers) | [512, 1024) exchange buffers [2][32 rows][8 features]
+      // LDS-DMA one group ahead (two buffers) | [512, 1088) exchange buffers [2][32 rows][stride 9: 8 features] (stride 8 puts the four
+      // row quads of a 16-lane write group on the same banks: SQ_LDS_BANK_CONFLICT was 70 % of the kernel's active LDS cycles)
       double* const zst = area;
       double* const xbuf = area + 512;
       const double* zsrc = p.Zaug + ((long)mt * TILE + wcol0 + (lm >> 2)) * p.CZp + 2 * (lm & 3);   // DMA i: rows 16 i + (lane >> 2), 16-byte piece lane & 3
@@ -1174,14 +1175,14 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
           }
           mfma_drain(h[1][1]);
           acc_fence<2>(h[0]); acc_fence<2>(h[1]);
-          double* xb = xbuf + xpar * 256;                   // [32 rows][8 features]: this wave's partial over its 32 columns
+          double* xb = xbuf + xpar * 288;                   // [32 rows][8 features, row stride 9]: this wave's partial over its 32 columns
 #pragma unroll
-          for (int t = 0; t < 2; ++t) { xb[(16 * t + srow) * 8 + lj] = h[t][0]; xb[(16 * t + srow) * 8 + 4 + lj] = h[t][1]; }
+          for (int t = 0; t < 2; ++t) { xb[(16 * t + srow) * 9 + lj] = h[t][0]; xb[(16 * t + srow) * 9 + 4 + lj] = h[t][1]; }
           __syncthreads();
           double s0 = 0.0;
 #pragma unroll
           for (int w4 = 0; w4 < 4; ++w4)                    // partials in column order: (wc, half) = (0,0), (0,1), (1,0), (1,1)
-            s0 += lds[(2 * wr + (w4 >> 1) + 4 * (w4 & 1)) * 1280 + 512 + xpar * 256 + rrow * 8 + rcol];
+            s0 += lds[(2 * wr + (w4 >> 1) + 4 * (w4 & 1)) * 1280 + 512 + xpar * 288 + rrow * 9 + rcol];
           if (8 * g + rcol < p.CZp) p.HZp[((long)mt * p.Np + n0 + wrow0 + 32 * pr + rrow) * p.CZp + 8 * g + rcol] = s0;
           xpar ^= 1;
         }

@@ -25,16 +25,17 @@ P2_KERNEL = 'gp::p2_fast8_kernel<3>'   # the dominant kernel at the default conf
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 (vector = matrix); ubench ceiling 74 (profiles/r01_ubench_f64_mfma4x4x4.txt)
 
 
-def synthetic(N, D, M, Q, seed, regime='A'):
-    """SURVEY.md 8(d) synthetic shard; generated with numpy on the host, outside the timed region."""
+def synthetic(N, D, M, Q, seed, regime='A', z_seed=None):
+    """SURVEY.md 8(d) synthetic shard; generated with numpy on the host, outside the timed region.  ``z_seed`` (None = the benchmark's
+    own inducing points) draws another set of inducing points: the parity fixtures cover several (tests/golden/make_hp_truth_large.py)."""
     rs = np.random.RandomState(seed)
     X = rs.randn(N, Q)
     W = np.random.RandomState(1234).randn(Q, D)          # same map on every rank
     Y = np.sin(X.dot(W)) + 0.1 * rs.randn(N, D)
     X_mu = X + 0.05 * rs.randn(N, Q)
     X_S = np.zeros((N, Q)) if regime == 'A' else rs.uniform(0.05, 0.55, size=(N, Q))   # SURVEY.md 8(d)
-    rz = np.random.RandomState(1)
-    Z = np.random.RandomState(0).randn(4 * M, Q)[rz.permutation(4 * M)[:M]] + 0.05 * rz.randn(M, Q)   # same Z on every rank
+    rz = np.random.RandomState(1 if z_seed is None else 2 * z_seed + 1)
+    Z = np.random.RandomState(0 if z_seed is None else 2 * z_seed).randn(4 * M, Q)[rz.permutation(4 * M)[:M]] + 0.05 * rz.randn(M, Q)   # same Z on every rank
     return dict(Y=Y, X_mu=X_mu, X_S=X_S, Z=Z, sf2=1.0, alpha=np.full(Q, 0.1), beta=10.0)
 
 

@@ -183,6 +183,16 @@ extern "C" int gp_destroy(gp_ctx* c) {
   return GP_OK;
 }
 
+extern "C" int gp_memory_info(gp_ctx* c, int64_t* free_bytes, int64_t* total_bytes) {
+  if (!c) return GP_ERR_BAD_ARG;
+  GP_HIP(c, hipSetDevice(c->device));
+  size_t f = 0, t = 0;
+  GP_HIP(c, hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return GP_OK;
+}
+
 extern "C" int gp_set_stream(gp_ctx* c, void* s) {
   if (!c) return GP_ERR_BAD_ARG;
   c->stream = (hipStream_t)s;

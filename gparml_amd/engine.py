@@ -208,6 +208,12 @@ class ShardEngine(object):
         return dict(generate_ms=t[0], phase1_ms=t[1], global_ms=t[2], phase2_ms=t[3], total_ms=t[4],
                     psi1_ms=t[5], p1_kernel_ms=t[6], p2_kernel_ms=t[7])
 
+    def memory_info(self):
+        """(free, total) bytes of the engine's device right now (hipMemGetInfo)."""
+        f, t = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(self.lib.gp_memory_info(self.h, ctypes.byref(f), ctypes.byref(t)), 'gp_memory_info')
+        return f.value, t.value
+
     # ---- results ------------------------------------------------------------------------------------
     _SHAPES = {
         'KMM': lambda s: (s.M, s.M), 'KMM_INV': lambda s: (s.M, s.M), 'PSI1': lambda s: (s.N_s, s.M),

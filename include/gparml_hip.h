@@ -148,6 +148,10 @@ int gp_set_local_statistics(gp_ctx* ctx, double sum_YYT, const double* Psi2, con
  * out[0]=prep+Psi1 generation, [1]=phase-1 contraction+reduce, [2]=global step, [3]=phase 2, [4]=sum of [0..3],
  * out[5]=psi1_kernel alone, [6]=p1_kernel alone, [7]=p2_kernel alone */
 int gp_last_timings(gp_ctx* ctx, double* out8);
+/* hipMemGetInfo of ctx's device: bytes free / total right now (the footprint of a shard at BASELINE configs[4]'s per-GPU size is
+ * OBSERVED with this; the reference has no counterpart -- its shard lives in the mapper process' numpy arrays,
+ * local_MapReduce.py:197-201) */
+int gp_memory_info(gp_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 
 /* partial_terms.grad_Z (which=0, partial_terms.py:207-240) / grad_alpha (which=1, :286-299) from explicitly given parts --
  * the signature an unmodified parallel_GPLVM.calculate_global_derivatives (:340-351) calls.  Shapes as in the reference:

@@ -19,7 +19,9 @@ must reproduce, truth_{F, grad_Z, grad_alpha, grad_sf2, grad_beta}, truth_uncert
 block's largest magnitude), cond(Kmm), cond(Kmm + beta Psi2).  Inputs are NOT stored: tests regenerate them with
 bench.synthetic(N, D, M, Q, seed=100) and check the checksums.
 
-Usage (build container, 8 cores: ~10 min at N = 1e6):  python tests/golden/make_hp_truth_large.py [N]
+Usage (build container, 8 cores: ~10 min at N = 1e6):  python tests/golden/make_hp_truth_large.py [N [seed [z_seed]]]
+(seed 100 with the benchmark's own inducing points is the default and keeps the file name hp_truth_large_N<N>.npz; other draws are
+stored as hp_truth_large_N<N>_s<seed>_z<z_seed>.npz -- round 4: four more data / inducing-point draws at both sizes)
 """
 import os
 import subprocess
@@ -60,8 +62,10 @@ def main():
     import bench
     from oracle import factorised as Fz
     N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
-    D, M, Q, seed = 100, 512, 10, 100
-    d = bench.synthetic(N, D, M, Q, seed=seed)
+    D, M, Q = 100, 512, 10
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    z_seed = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    d = bench.synthetic(N, D, M, Q, seed=seed, z_seed=z_seed)
     assert np.all(d['X_S'] == 0)
     exe = os.path.join(ROOT, 'oracle', '_build', 'hp_truth')
     os.makedirs(os.path.dirname(exe), exist_ok=True)
@@ -74,7 +78,8 @@ def main():
     print('[hp-large] long-double truth: %.0f s' % (time.time() - t0))
     tru, tru_lo = unpack(np.fromfile(work + '/truth_plain.bin'), M, Q)
     rev, rev_lo = unpack(np.fromfile(work + '/truth_reversed.bin'), M, Q)
-    save = dict(N=np.int64(N), D=np.int64(D), M=np.int64(M), Q=np.int64(Q), seed=np.int64(seed), input_checksums=checksums(d))
+    save = dict(N=np.int64(N), D=np.int64(D), M=np.int64(M), Q=np.int64(Q), seed=np.int64(seed), z_seed=np.int64(-1 if z_seed is None else z_seed),
+                input_checksums=checksums(d))
     unc = {}
     for k in BLOCKS:
         save['truth_' + k] = np.asarray(tru[k], dtype=np.float64)
@@ -100,7 +105,7 @@ def main():
             save['err_%s_%s' % (name, tag)] = np.float64(rel(o['gstep'][key], part[tag]))
         print('[hp-large] float64 %-8s (%.0f s): ' % (linalg, time.time() - t0) +
               '  '.join('%s %.2e' % (k, save['err_%s_%s' % (name, k)]) for k in BLOCKS + ('Abar', 'Bbar', 'dFdK')))
-    out = os.path.join(HERE, 'hp_truth_large_N%d.npz' % N)
+    out = os.path.join(HERE, 'hp_truth_large_N%d%s.npz' % (N, '' if (seed, z_seed) == (100, None) else '_s%d_z%d' % (seed, -1 if z_seed is None else z_seed)))
     np.savez_compressed(out, **save)
     print('[hp-large] wrote', out, os.path.getsize(out), 'bytes;  scratch in', work)
 

@@ -179,6 +179,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 4; ++i) if (c->gev[i]) (void)hipEventDestroy(c->gev[i]);
   if (c->side) (void)hipStreamDestroy(c->side);
+  for (int i = 0; i < 2; ++i) { if (c->h_glob[i]) (void)hipHostFree(c->h_glob[i]); if (c->glob_ev[i]) (void)hipEventDestroy(c->glob_ev[i]); }
   delete c;
   return GP_OK;
 }
@@ -289,11 +290,25 @@ extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const doub
   if (N_global < c->N) return fail(c, GP_ERR_BAD_ARG, "N_global (%ld) smaller than the local shard (%ld)", (long)N_global, (long)c->N);
   GP_HIP(c, hipSetDevice(c->device));
   double* tmp = c->T1;  // scratch for the unpadded Z
-  GP_HIP(c, hipMemcpyAsync(tmp, Z, (size_t)c->M * c->Q * 8, hipMemcpyHostToDevice, c->stream));
-  GP_HIP(c, hipMemcpyAsync(c->alpha, alpha, (size_t)c->Q * 8, hipMemcpyHostToDevice, c->stream));
+  // stage through pinned memory: hipMemcpyAsync from pageable memory blocks the host until the copy has been staged AND used to be followed by a
+  // stream synchronisation here (r03: every evaluation of an optimiser paid it); from a pinned slot the copy is asynchronous and the call returns
+  // after enqueueing -- the evaluation's only host synchronisation is the read-back in gp_finish
+  const size_t nz = (size_t)c->M * c->Q, nq = (size_t)c->Q;
+  const int slot = c->glob_slot;
+  if (!c->h_glob[slot]) {
+    GP_HIP(c, hipHostMalloc((void**)&c->h_glob[slot], (nz + nq) * sizeof(double), hipHostMallocDefault));
+    GP_HIP(c, hipEventCreateWithFlags(&c->glob_ev[slot], hipEventDisableTiming));
+  } else {
+    GP_HIP(c, hipEventSynchronize(c->glob_ev[slot]));   // the copy issued from this slot two calls ago (long complete in any real sequence)
+  }
+  std::memcpy(c->h_glob[slot], Z, nz * sizeof(double));
+  std::memcpy(c->h_glob[slot] + nz, alpha, nq * sizeof(double));
+  GP_HIP(c, hipMemcpyAsync(tmp, c->h_glob[slot], nz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipMemcpyAsync(c->alpha, c->h_glob[slot] + nz, nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  GP_HIP(c, hipEventRecord(c->glob_ev[slot], c->stream));
+  c->glob_slot = slot ^ 1;
   hipLaunchKernelGGL(zaug_kernel, dim3((c->Mp + 255) / 256), dim3(256), 0, c->stream, tmp, c->M, c->Mp, c->Q, c->CZp, c->Z, c->Zaug);
   GP_HIP(c, hipGetLastError());
-  GP_HIP(c, hipStreamSynchronize(c->stream));
   c->sf2 = sf2; c->beta = beta; c->N_global = N_global; c->step = step;
   c->have_globals = true;
   c->state = 0;
@@ -312,6 +327,7 @@ extern "C" int gp_phase1(gp_ctx* c) {
   if (!c->regime_A) GP_TRY(run_phase1_b(c));
   GP_HIP(c, hipEventRecord(c->ev[2], c->stream));
   c->state = 1;
+  c->spack_filled = false;
   return GP_OK;
 }
 
@@ -323,26 +339,35 @@ extern "C" int gp_stats_buffer(gp_ctx* c, void** dev_ptr, int64_t* n) {
 }
 
 // ---- packed statistics for the all-reduce across processes: Psi2 upper triangle (row-major) | C [M][D] | scalars
-__global__ void __launch_bounds__(256) stats_pack_kernel(const double* __restrict__ stats, double* __restrict__ pk, int M, int Mp, int D, int Dp, int unpack_) {
+// element e of the packed payload <-> its place in the padded statistics buffer (second index: the mirrored Psi2 element, or -1)
+__device__ __forceinline__ bool spack_map(long e, int M, int Mp, int D, int Dp, long* k, long* s0, long* s1) {
   const long tri = (long)M * (M + 1) / 2, md = (long)M * D;
-  double* st = const_cast<double*>(stats);
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)M * M + md + SC_COUNT; e += (long)gridDim.x * 256L) {
-    if (e < (long)M * M) {
-      const int i = (int)(e / M), j = (int)(e - (long)i * M);
-      if (j < i) continue;
-      const long k = (long)i * M - (long)i * (i - 1) / 2 + (j - i);
-      if (unpack_) { const double v = pk[k]; st[(long)i * Mp + j] = v; st[(long)j * Mp + i] = v; }
-      else pk[k] = stats[(long)i * Mp + j];
-    } else if (e < (long)M * M + md) {
-      const long r = e - (long)M * M;
-      const int i = (int)(r / D), d = (int)(r - (long)i * D);
-      if (unpack_) st[(long)Mp * Mp + (long)i * Dp + d] = pk[tri + r];
-      else pk[tri + r] = stats[(long)Mp * Mp + (long)i * Dp + d];
-    } else {
-      const long r = e - (long)M * M - md;
-      if (unpack_) st[(long)Mp * Mp + (long)Mp * Dp + r] = pk[tri + md + r];
-      else pk[tri + md + r] = stats[(long)Mp * Mp + (long)Mp * Dp + r];
-    }
+  *s1 = -1;
+  if (e < (long)M * M) {
+    const int i = (int)(e / M), j = (int)(e - (long)i * M);
+    if (j < i) return false;
+    *k = (long)i * M - (long)i * (i - 1) / 2 + (j - i);
+    *s0 = (long)i * Mp + j; *s1 = (long)j * Mp + i;
+  } else if (e < (long)M * M + md) {
+    const long r = e - (long)M * M;
+    const int i = (int)(r / D), d = (int)(r - (long)i * D);
+    *k = tri + r; *s0 = (long)Mp * Mp + (long)i * Dp + d;
+  } else {
+    const long r = e - (long)M * M - md;
+    *k = tri + md + r; *s0 = (long)Mp * Mp + (long)Mp * Dp + r;
+  }
+  return true;
+}
+__global__ void __launch_bounds__(256) stats_pack_kernel(const double* __restrict__ stats, double* __restrict__ pk, int M, int Mp, int D, int Dp) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)M * M + (long)M * D + SC_COUNT; e += (long)gridDim.x * 256L) {
+    long k, s0, s1;
+    if (spack_map(e, M, Mp, D, Dp, &k, &s0, &s1)) pk[k] = stats[s0];
+  }
+}
+__global__ void __launch_bounds__(256) stats_unpack_kernel(const double* __restrict__ pk, double* __restrict__ stats, int M, int Mp, int D, int Dp) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)M * M + (long)M * D + SC_COUNT; e += (long)gridDim.x * 256L) {
+    long k, s0, s1;
+    if (spack_map(e, M, Mp, D, Dp, &k, &s0, &s1)) { const double v = pk[k]; stats[s0] = v; if (s1 >= 0) stats[s1] = v; }
   }
 }
 static int64_t spack_doubles(const gp_ctx* c) { return (int64_t)c->M * (c->M + 1) / 2 + (int64_t)c->M * c->D + SC_COUNT; }
@@ -367,7 +392,14 @@ static int stats_pack(gp_ctx* c, int unpack_) {
   GP_HIP(c, hipSetDevice(c->device));
   GP_TRY(ensure_spack(c));
   const long n = (long)c->M * c->M + (long)c->M * c->D + SC_COUNT;
-  hipLaunchKernelGGL(stats_pack_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, (const double*)c->stats, c->spack, c->M, c->Mp, c->D, c->Dp, unpack_);
+  if (unpack_) {
+    // the packed buffer only holds statistics after a pack (it is zero from its allocation): unpacking first would silently wipe phase 1's sums
+    if (!c->spack_filled) return fail(c, GP_ERR_STATE, "gp_stats_unpack before gp_stats_pack");
+    hipLaunchKernelGGL(stats_unpack_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, (const double*)c->spack, c->stats, c->M, c->Mp, c->D, c->Dp);
+  } else {
+    hipLaunchKernelGGL(stats_pack_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, (const double*)c->stats, c->spack, c->M, c->Mp, c->D, c->Dp);
+    c->spack_filled = true;
+  }
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }

@@ -79,6 +79,7 @@ struct gp_ctx {
   bool stats_external = false;
   double* spack = nullptr;    // Psi2 upper triangle | C [M][D] | scalars: the all-reduce payload across processes (allocated on first use)
   double* grads = nullptr;    // packed: gZ_data [M*Q] | galpha_data [Q]
+  bool spack_filled = false;  // gp_stats_pack has run since the last gp_phase1 (gp_stats_unpack refuses to run before it)
   bool grads_external = false;
   double* staging = nullptr;  // landing buffer for a peer copy from a shard on another device (gp_buffer_combine)
   size_t staging_doubles = 0;
@@ -166,6 +167,11 @@ struct gp_ctx {
   // global step: a second stream for the product chain that does not depend on the other one (created on first use), fork / join events
   hipStream_t side = nullptr;
   hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // gp_set_globals: pinned host staging (two slots, [M*Q + Q] doubles each) so that the upload of Z and alpha is a true asynchronous copy --
+  // an evaluation then has ONE host synchronisation, the read-back in gp_finish; the slot's event guards its reuse two calls later
+  double* h_glob[2] = {nullptr, nullptr};
+  hipEvent_t glob_ev[2] = {nullptr, nullptr};
+  int glob_slot = 0;
   // timing
   hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double t_ms[5] = {0, 0, 0, 0, 0};

@@ -149,6 +149,47 @@ __global__ void __launch_bounds__(512) solve_residual_kernel(const double* __res
   }
 }
 
+// C = A B with the products error-free (FMA) and the sums carried in double-double (two-sum), rounded to double once at the end.
+// A [rows][K] row-major with the wave's RB rows wave-uniform (scalar loads), B [K][cols] row-major (lane = column: coalesced), both float64.
+// Used for G = K_mm^-1 Psi2, the one product of the global step whose float64 ACCUMULATION carries the whole remaining error of grad_Z at the
+// benchmark's conditioning: K_mm^-1 has entries of both signs around 1e5, Psi2 entries around N, and the product is (K_mm^-1 A - I) / beta -- a
+// small difference.  With this one product accumulated in double-double (inputs and output float64, everything else as before) grad_Z's
+// distance from the 80-bit truth drops from 1.1e-5 to 1.6e-8 at N = 1e5 and stays at 1e-8 .. 2e-8 for every data / inducing-point draw tried
+// (the same arithmetic emulated with numpy error-free transformations before it was built).  No extended-precision inverse,
+// no Newton step, no double-double storage is needed.  1024 waves at M = 512 with RB = 4; the four waves of a workgroup share their column
+// block, so B's rows are read from L2 once per workgroup.
+template <int RB, int KU>
+__global__ void __launch_bounds__(256) ddacc_gemm_kernel(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int K,
+                                                          double* __restrict__ C, long ldc) {
+#pragma clang fp contract(off)   // hi + a b as one FMA would break the two-sum
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + lane;
+  const int i0 = (blockIdx.y * 4 + wave) * RB;
+  double hi[RB], lo[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) { hi[r] = 0.0; lo[r] = 0.0; }
+  const double* bp = B + j;
+  const double* ap = A + (long)i0 * lda;
+  for (int k = 0; k < K; k += KU) {
+    double bv[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) bv[u] = bp[(long)(k + u) * ldb];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const double a = ap[(long)r * lda + k + u];              // wave-uniform: a scalar load
+        const double pr = a * bv[u], pe = fma(a, bv[u], -pr);    // a b = pr + pe exactly
+        const double t = hi[r] + pr, bb = t - hi[r];             // two-sum
+        lo[r] += ((hi[r] - (t - bb)) + (pr - bb)) + pe;
+        hi[r] = t;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) C[(long)(i0 + r) * ldc + j] = hi[r] + lo[r];
+}
+
 // sum over the M x M (or M x D) block of x o y; one block per pair, results into out[slot]
 struct DotJob { const double* x; const double* y; long ld; int rows, cols; int slot; };
 struct DotJobs { DotJob j[8]; int n; };
@@ -362,8 +403,24 @@ int run_global_step(gp_ctx* c) {
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
   { const int sps = g.splits; if ((Dp / KC) % kSplitK != 0 || Dp < 256) g.splits = 1; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
-  g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
-  launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+  // G = Ki Psi2 with double-double accumulation (ddacc_gemm_kernel above; GPARML_DD_KIPSI2=0: the float64 matrix-core product of r03)
+  static const bool dd_G = [] { const char* e = getenv("GPARML_DD_KIPSI2"); return !(e && e[0] == '0'); }();
+  if (dd_G) {
+    static const int variant = [] { const char* e = getenv("GPARML_DD_VARIANT"); return e ? atoi(e) : 0; }();
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((ddacc_gemm_kernel<4, 8>), dim3(Mp / 64, Mp / 16), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
+      case 2: hipLaunchKernelGGL((ddacc_gemm_kernel<2, 4>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
+      case 3: hipLaunchKernelGGL((ddacc_gemm_kernel<2, 8>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
+      case 4: hipLaunchKernelGGL((ddacc_gemm_kernel<8, 4>), dim3(Mp / 64, Mp / 32), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
+      case 5: hipLaunchKernelGGL((ddacc_gemm_kernel<1, 8>), dim3(Mp / 64, Mp / 4), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
+      default: hipLaunchKernelGGL((ddacc_gemm_kernel<4, 4>), dim3(Mp / 64, Mp / 16), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
+    }
+    GP_HIP(c, hipGetLastError());
+  } else {
+    g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
+    launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+  }
+  g.K = Mp;
   g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;
   launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   if (two) { GP_HIP(c, hipEventRecord(c->gev[1], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[1], 0)); }

@@ -490,7 +490,9 @@ int run_phase2_b_tiles(gp_ctx* c) {
   const int T = c->n_tiles64, Q = c->Q, PW = 3 * Q + 1;
   const long N = c->N;
   // points per launch: the per-tile sums of a launch live in pp [T][PW][CH] (<= 1.5 GB)
-  if (!c->ppt) {
+  if (!c->ppt || !c->Gt) {
+    if (c->ppt) { (void)hipFree(c->ppt); c->ppt = nullptr; }
+    if (c->Gt) { (void)hipFree(c->Gt); c->Gt = nullptr; }
     long ch = std::min<long>(N, 8192);
     while (ch > 512 && (double)T * PW * ch * 8.0 > 1.5e9) ch /= 2;
     c->b_ch = ch;
@@ -501,8 +503,14 @@ int run_phase2_b_tiles(gp_ctx* c) {
       if (eff > best + 0.02) { best = eff; bestS = S; }
     }
     c->b_S = bestS;
+    // both or neither: a failed second allocation must not leave the first behind (the next call would skip this block and launch with a null Gt).
+    // Neither buffer needs zeroing: the first launch of an evaluation (accumulate = 0) writes every pp[t][i][k < count] and all T * S
+    // workgroups store their Gt slot unconditionally.
     GP_HIP(c, hipMalloc((void**)&c->ppt, (size_t)T * PW * ch * sizeof(double)));
-    GP_HIP(c, hipMalloc((void**)&c->Gt, (size_t)bestS * T * 2 * 64 * Q * sizeof(double)));
+    if (hipMalloc((void**)&c->Gt, (size_t)bestS * T * 2 * 64 * Q * sizeof(double)) != hipSuccess) {
+      (void)hipFree(c->ppt); c->ppt = nullptr; c->Gt = nullptr;
+      return fail(c, GP_ERR_HIP, "regime-B tile phase 2: allocation of the grad_Z partial buffer failed");
+    }
   }
   PT2Args a;
   a.ZP = c->ZP; a.Bbar = c->Bbar; a.LEA = c->LET; a.V2P = c->V2P; a.WP = c->WP; a.MUP = c->MUP; a.alphaP = c->alphaP;

@@ -327,9 +327,13 @@ def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixe
     Z2a = (Z * Z).dot(a)                                        # sum_q a_q z_mq^2
     Za = (Z * a[None, :]).T.copy()                              # (Q, M)
     if workers > 1:
+        import queue
         from multiprocessing.pool import ThreadPool
         pool = ThreadPool(workers)
         run = lambda f: pool.map(f, range(nch))
+        free_w = queue.Queue()                                  # one W buffer per pool thread, handed out per chunk (reused across calls)
+        for w in range(workers):
+            free_w.put(w)
     else:
         pool = None
         run = lambda f: [f(i) for i in range(nch)]
@@ -364,11 +368,16 @@ def evaluate_blas(Z, sf2, alpha, beta, Y, X_mu, N_global=None, chunk=32768, fixe
         def p2(i):
             lo, hi = i * chunk, min(N_s, (i + 1) * chunk)
             K, mu, Yc = work['K'][i], X_mu[lo:hi], Y[lo:hi]
-            W = work['W'][i % workers][:hi - lo] if workers == 1 else np.empty((hi - lo, M))
-            np.dot(K, B2, out=W)
-            W += Yc.dot(At)
-            W *= K                                                  # W = G o K
-            return W.T.dot(mu), W.sum(0), W.sum(1).dot(mu * mu)
+            wid = 0 if workers == 1 else free_w.get()
+            try:
+                W = work['W'][wid][:hi - lo]
+                np.dot(K, B2, out=W)
+                W += Yc.dot(At)
+                W *= K                                              # W = G o K
+                return W.T.dot(mu), W.sum(0), W.sum(1).dot(mu * mu)
+            finally:
+                if workers > 1:
+                    free_w.put(wid)
 
         parts = run(p2)
     finally:

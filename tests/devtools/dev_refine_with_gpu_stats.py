@@ -1,6 +1,6 @@
 """Dev experiment (GPU box): the device's own statistics (Psi2, Psi1^T Y as the MFMA kernels accumulate them) through global steps of
 increasing precision on the host -- where is the floor of grad_Z at the benchmark's conditioning, and how far is the device's float64 global
-step from it?  Usage: python tests/devtools/dev_refine_with_gpu_stats.py [N]"""
+step from it?  Usage: python tests/devtools/dev_refine_with_gpu_stats.py [N [seed [z_seed]]]"""
 import os, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,10 @@ from gparml_amd.engine import ShardEngine
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100000
 D, M, Q = 100, 512, 10
-d = bench.synthetic(N, D, M, Q, seed=100)
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ZSEED = int(sys.argv[3]) if len(sys.argv) > 3 else None
+print('N %d seed %d z_seed %s' % (N, SEED, ZSEED), flush=True)
+d = bench.synthetic(N, D, M, Q, seed=SEED, z_seed=ZSEED)
 exe = os.path.join(ROOT, 'oracle', '_build', 'hp_truth')
 os.makedirs(os.path.dirname(exe), exist_ok=True)
 subprocess.check_call(['gcc', '-O2', '-fopenmp', '-o', exe, os.path.join(ROOT, 'oracle', 'hp_truth.c'), '-lm'])

@@ -14,7 +14,9 @@ if [ "$1" == "--asm" ]; then
   done
   exit 0
 fi
-OBJ="$ROOT/build/obj${GPARML_OBJ_TAG}"
+# the object cache is keyed on the compile flags: an ablation / timing build (GPARML_EXTRA_FLAGS=-D...) never reuses production objects
+FTAG=$(echo "$FLAGS" | md5sum | cut -c1-8)
+OBJ="$ROOT/build/obj${GPARML_OBJ_TAG}-$FTAG"
 mkdir -p "$OBJ"
 newest_hdr=$(ls -t "$SRC"/*.h "$ROOT"/include/*.h | head -1)
 pids=()
@@ -27,5 +29,8 @@ for f in "$SRC"/*.hip; do
   fi
 done
 for p in "${pids[@]}"; do wait $p || { echo "build failed"; exit 1; }; done
-hipcc --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$OUT"
+# link exactly the objects of the current sources (a deleted or renamed .hip leaves a stale object behind)
+objs=()
+for f in "$SRC"/*.hip; do objs+=("$OBJ/$(basename "$f" .hip).o"); done
+hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT"
 ls -la "$OUT"

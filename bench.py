@@ -100,6 +100,30 @@ def truth_errors(d, out, N, D, M, Q, seed):
     return res
 
 
+def extended_precision_cost(eng, d, N, D, M, Q, seed):
+    """Global-step device time and grad_Z's distance from the extended-precision truth for three settings of the global step: float64 only,
+    + one double-double refinement step of E (round 3), + K_mm^-1 Psi2 accumulated in double-double (round 4, the default)."""
+    from gparml_amd import _lib
+    lib = _lib.load()
+    res = {}
+    try:
+        for name, dd, ref in (('float64', 0, 0), ('refine_E', 0, 1), ('refine_E+dd_KiPsi2 (default)', 1, 1)):
+            lib.gp_debug_set_option(b'dd_kipsi2', dd)
+            lib.gp_debug_set_option(b'refine_E', ref)
+            eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
+            g = []
+            for _ in range(4):
+                out = eng.evaluate(False)
+                g.append(eng.timings()['global_ms'])
+            te = truth_errors(d, out, N, D, M, Q, seed)
+            res[name] = {'global_ms': round(min(g[1:]), 4), 'grad_Z_err_vs_truth': None if te is None else te['grad_Z_err_vs_truth']}
+    finally:
+        lib.gp_debug_set_option(b'dd_kipsi2', 1)
+        lib.gp_debug_set_option(b'refine_E', 1)
+    res['cost_ms'] = round(res['refine_E+dd_KiPsi2 (default)']['global_ms'] - res['float64']['global_ms'], 4)
+    return res
+
+
 def regime_b_extra(name, N, D, M, Q, device, steps=2, threaded=False):
     """One free-embedding (Bayesian GPLVM, regime B) evaluation shape, timed OUTSIDE the headline region: ms per evaluation (HIP
     events on the engine's stream), SURVEY.md 8(d)'s W_B = N M^2 (4Q + 10) and its fraction of the FP64 peak, the dominant kernels."""
@@ -377,8 +401,12 @@ def main():
             res['config']['allreduce_ms']['total'] = round(sum(coll.values()), 4)
             res['config']['global_ms'] = round(kern['global_ms'], 4)
             res['config']['ms_per_step_by_rank'] = {'min': round(min(rank_ms), 4), 'max': round(max(rank_ms), 4), 'all': [round(v, 4) for v in rank_ms]}
-        res['config']['global_step'] = ('float64 blocked Cholesky + inverses; E = (Kmm + beta Psi2)^-1 Psi1^T Y refined once with a double-double residual'
-                                        if os.environ.get('GPARML_REFINE_E', '1') != '0' else 'float64 blocked Cholesky + inverses (GPARML_REFINE_E=0)')
+        res['config']['global_step'] = ('float64 blocked Cholesky + inverses; Kmm^-1 Psi2 accumulated in double-double; E = (Kmm + beta Psi2)^-1 Psi1^T Y '
+                                        'refined once with a double-double residual (GPARML_DD_KIPSI2 / GPARML_REFINE_E = 0 switch them off)')
+        if a.regime == 'A' and world == 1:
+            # the price of the two extended-precision pieces: the global step timed (HIP events) with and without them, after the timed region,
+            # with grad_Z's distance from the truth for each setting
+            res['config']['extended_precision_cost'] = extended_precision_cost(eng, d, N, D, M, Q, 100 + rank)
         if a.regime == 'A':
             # parity of THIS run's last evaluation against the extended-precision truth of the same workload (rank 0's shard alone:
             # only meaningful for one shard), and the conditioning it was obtained at

@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPARML_LIB: another build of the same library (tools/ab_bench.sh runs variants side by side without touching the in-tree one)
 LIB_PATH = os.environ.get('GPARML_LIB') or os.path.join(_HERE, 'libgparml_hip.so')
 
-GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_ERR_HIP, GP_ERR_STATE, GP_ERR_UNSUPPORTED, GP_RETRY_JITTER = range(8)
+GP_OK, GP_ERR_BAD_ARG, GP_ERR_NOT_PD, GP_ERR_NON_FINITE, GP_ERR_HIP, GP_ERR_STATE, GP_ERR_UNSUPPORTED, GP_RETRY_JITTER, GP_ERR_RCCL = range(9)
+GP_COMM_ID_BYTES = 128
 
 # gp_download selectors (include/gparml_hip.h)
 ARR = dict(KMM=0, KMM_INV=1, PSI1=2, PSI2_SUM=3, PSI1TY=4, KMM_PLUS_OP_INV=5, DF_DKMM=6, DF_DPSI1TY=7, DF_DPSI2=8,
@@ -45,6 +46,10 @@ SIGNATURES = {
     'gp_global_step_jitter': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gp_global_status': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     'gp_phase2': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'gp_comm_unique_id': (ctypes.c_int, [_vp]),
+    'gp_comm_init': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'gp_allreduce': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'gp_comm_destroy': (ctypes.c_int, [_vp]),
     'gp_grads_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     'gp_finish': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     'gp_download': (ctypes.c_int, [_vp, ctypes.c_int, _dp, _i64]),
@@ -58,6 +63,7 @@ SIGNATURES = {
     'gp_cg_abs': (ctypes.c_int, [_vp, _dp]),
     'gp_cg_update': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
     'gp_debug_gemm': (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_double, _dp, _dp, ctypes.c_double, _dp]),
+    'gp_debug_set_option': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'gp_debug_potrf_inverse': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
 }
 

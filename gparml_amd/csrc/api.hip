@@ -176,6 +176,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (c->bmap) (void)hipFree(c->bmap);
   if (c->staging) (void)hipFree(c->staging);
   gp::p1v2_free(c);
+  gp::comm_free(c);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 4; ++i) if (c->gev[i]) (void)hipEventDestroy(c->gev[i]);
   if (c->side) (void)hipStreamDestroy(c->side);

@@ -167,6 +167,9 @@ struct gp_ctx {
   // global step: a second stream for the product chain that does not depend on the other one (created on first use), fork / join events
   hipStream_t side = nullptr;
   hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // RCCL communicator of this context's rank (comm.hip; NULL until gp_comm_init)
+  void* comm = nullptr;
+  int comm_ranks = 0, comm_rank = -1;
   // gp_set_globals: pinned host staging (two slots, [M*Q + Q] doubles each) so that the upload of Z and alpha is a true asynchronous copy --
   // an evaluation then has ONE host synchronisation, the read-back in gp_finish; the slot's event guards its reuse two calls later
   double* h_glob[2] = {nullptr, nullptr};
@@ -201,6 +204,8 @@ bool pt2_applicable(const gp_ctx* c, bool sym_available);
 int run_phase2_b_tiles(gp_ctx* c);
 // compat.hip
 int compat_build(gp_ctx* c, int which, double** out, long* count);
+// comm.hip
+void comm_free(gp_ctx* c);
 // linalg.hip
 int run_global_step(gp_ctx* c);
 int check_global(gp_ctx* c);
@@ -212,6 +217,7 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
                           double* splitk_ws /*may be NULL*/);
 }  // namespace gp
 
+#define GP_TRY_RC(x) do { int rc__ = (x); if (rc__ != GP_OK) return rc__; } while (0)
 #define GP_HIP(ctx, call)                                                                         \
   do {                                                                                            \
     hipError_t e__ = (call);                                                                      \

@@ -8,10 +8,18 @@
 #include "gp_common.h"
 #include "potrf128.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace gp {
+
+// switches of the global step's extended-precision pieces (default on; environment at load time, gp_debug_set_option at run time: bench.py
+// prices them by timing the global step with and without)
+static bool env_on(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
+std::atomic<int> g_opt_dd_kipsi2{env_on("GPARML_DD_KIPSI2") ? 1 : 0};
+std::atomic<int> g_opt_refine_E{env_on("GPARML_REFINE_E") ? 1 : 0};
 
 constexpr int kSplitK = 8;   // split-k factor of the M x M x M products of the global step (latency-bound: 16 tiles alone fill 6 % of the chip)
 
@@ -389,8 +397,7 @@ int run_global_step(gp_ctx* c) {
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   // one refinement step of E with a double-double residual (PsiE is free until the next product); GPARML_REFINE_E=0 turns it off
-  static const bool refine_E = [] { const char* e = getenv("GPARML_REFINE_E"); return !(e && e[0] == '0'); }();
-  if (refine_E) {
+  if (g_opt_refine_E.load()) {
     hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(512), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
                        c->PsiE, 0);
     GP_HIP(c, hipGetLastError());
@@ -403,18 +410,11 @@ int run_global_step(gp_ctx* c) {
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
   { const int sps = g.splits; if ((Dp / KC) % kSplitK != 0 || Dp < 256) g.splits = 1; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
-  // G = Ki Psi2 with double-double accumulation (ddacc_gemm_kernel above; GPARML_DD_KIPSI2=0: the float64 matrix-core product of r03)
-  static const bool dd_G = [] { const char* e = getenv("GPARML_DD_KIPSI2"); return !(e && e[0] == '0'); }();
-  if (dd_G) {
-    static const int variant = [] { const char* e = getenv("GPARML_DD_VARIANT"); return e ? atoi(e) : 0; }();
-    switch (variant) {
-      case 1: hipLaunchKernelGGL((ddacc_gemm_kernel<4, 8>), dim3(Mp / 64, Mp / 16), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
-      case 2: hipLaunchKernelGGL((ddacc_gemm_kernel<2, 4>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
-      case 3: hipLaunchKernelGGL((ddacc_gemm_kernel<2, 8>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
-      case 4: hipLaunchKernelGGL((ddacc_gemm_kernel<8, 4>), dim3(Mp / 64, Mp / 32), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
-      case 5: hipLaunchKernelGGL((ddacc_gemm_kernel<1, 8>), dim3(Mp / 64, Mp / 4), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
-      default: hipLaunchKernelGGL((ddacc_gemm_kernel<4, 4>), dim3(Mp / 64, Mp / 16), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp); break;
-    }
+  // G = Ki Psi2 with double-double accumulation (ddacc_gemm_kernel above: two rows per wave, eight k per trip -- same-box timing of six shapes
+  // in profiles/r04_dd_variants.txt: +50 us at M = 512, +9 us at M = 128, +0.29 ms at M = 1024 over the float64 matrix-core product of r03, which
+  // GPARML_DD_KIPSI2=0 or gp_debug_set_option("dd_kipsi2", 0) restores)
+  if (g_opt_dd_kipsi2.load()) {
+    hipLaunchKernelGGL((ddacc_gemm_kernel<2, 8>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp);
     GP_HIP(c, hipGetLastError());
   } else {
     g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
@@ -455,7 +455,15 @@ int run_global_step(gp_ctx* c) {
 
 }  // namespace gp
 
-// ---- test hook -------------------------------------------------------------------------------------------------
+// ---- test hooks ------------------------------------------------------------------------------------------------
+extern "C" int gp_debug_set_option(const char* name, int value) {
+  using namespace gp;
+  if (!name) return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: NULL name");
+  if (!std::strcmp(name, "dd_kipsi2")) { g_opt_dd_kipsi2.store(value ? 1 : 0); return GP_OK; }
+  if (!std::strcmp(name, "refine_E")) { g_opt_refine_E.store(value ? 1 : 0); return GP_OK; }
+  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E)", name);
+}
+
 extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet) {
   using namespace gp;
   gp_ctx tmp;

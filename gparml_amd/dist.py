@@ -25,6 +25,25 @@ def device_tensor(ptr, n, device):
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
+def init_native_comm(engine, dist, group=None):
+    """Give ``engine`` its own RCCL communicator (gp_comm_init): rank 0 draws the ncclUniqueId, torch.distributed carries the 128 bytes to
+    the other ranks, every rank joins.  Returns True when the engine now reduces inside the library (gp_allreduce); False when the
+    engine has no such entry point, the backend is not RCCL (gloo tests) or GPARML_NATIVE_ALLREDUCE=0 -- the caller then keeps using
+    torch.distributed on the device pointers."""
+    import os
+    if os.environ.get('GPARML_NATIVE_ALLREDUCE', '1') == '0' or not hasattr(engine, 'comm_init'):
+        return False
+    if not dist.is_initialized() or dist.get_backend(group) != 'nccl':
+        return False
+    if getattr(engine, 'has_comm', False):
+        return True
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(box[0], world, rank)
+    return True
+
+
 class DistributedEvaluator(object):
     """Drives one ShardEngine per rank through phase1 -> all-reduce -> global step -> phase2 -> all-reduce."""
 
@@ -42,6 +61,9 @@ class DistributedEvaluator(object):
         self._packed = False
         self.time_collectives = False     # bench.py: device-side time of the two all-reduces of the last evaluation
         self._cev = None
+        # the reduce inside the library (gp_allreduce: RCCL on the engine's stream) when the process group is RCCL; otherwise torch.distributed
+        # all-reduces the same device buffers (gloo in the CPU / one-device tests)
+        self.native = (self.world > 1 or self.force) and init_native_comm(engine, dist, group)
 
     def _tensors(self):
         if self._stats_t is None:
@@ -68,7 +90,8 @@ class DistributedEvaluator(object):
         gradients (embeddings_MR visits all nodes, local_MapReduce.py:293-295)."""
         eng = self.engine
         collective = self.world > 1 or self.force
-        stats_t, grads_t = self._tensors() if collective else (None, None)   # zero-copy torch views of the packed device buffers
+        native = collective and self.native
+        stats_t, grads_t = self._tensors() if (collective and not native) else (None, None)   # zero-copy torch views of the packed device buffers
         kept_here = True
         if kept_mask is not None:
             kept_mask = [bool(k) for k in kept_mask]
@@ -81,7 +104,13 @@ class DistributedEvaluator(object):
         eng.phase1()
         if not kept_here:
             eng.scale_buffer('stats', 0.0)
-        if collective:
+        if native:
+            if cev:
+                cev[0].record()
+            eng.allreduce('stats')            # pack -> ncclAllReduce -> unpack on the engine's stream
+            if cev:
+                cev[1].record()
+        elif collective:
             if self._packed:
                 eng.stats_pack()
             if cev:
@@ -102,7 +131,10 @@ class DistributedEvaluator(object):
             if collective:
                 if cev:
                     cev[2].record()
-                self.dist.all_reduce(grads_t, op=self.dist.ReduceOp.SUM, group=self.group)
+                if native:
+                    eng.allreduce('grads')
+                else:
+                    self.dist.all_reduce(grads_t, op=self.dist.ReduceOp.SUM, group=self.group)
                 if cev:
                     cev[3].record()
             if rescale:
@@ -128,7 +160,7 @@ class DistributedEvaluator(object):
         if not (self.time_collectives and self._cev):
             return {'allreduce_stats_ms': 0.0, 'allreduce_grads_ms': 0.0}
         import torch
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()      # free here: the evaluation's own read-back (gp_finish) has already waited for everything on the stream
         return {'allreduce_stats_ms': self._cev[0].elapsed_time(self._cev[1]), 'allreduce_grads_ms': self._cev[2].elapsed_time(self._cev[3])}
 
 

@@ -107,6 +107,31 @@ class ShardEngine(object):
         self._ck(self.lib.gp_grads_buffer(self.h, ctypes.byref(p), ctypes.byref(n)), 'gp_grads_buffer')
         return p.value, n.value
 
+    # ---- the reduce across GPUs inside the library (RCCL resolved with dlopen; include/gparml_hip.h gp_comm_*) -------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte ncclUniqueId (rank 0 calls this and hands the bytes to every other rank)."""
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(_lib.GP_COMM_ID_BYTES)
+        _lib.raise_for(lib.gp_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), lib, None, 'gp_comm_unique_id')
+        return buf.raw
+
+    def comm_init(self, unique_id, nranks, rank):
+        assert len(unique_id) == _lib.GP_COMM_ID_BYTES
+        buf = ctypes.create_string_buffer(bytes(unique_id), _lib.GP_COMM_ID_BYTES)
+        self._ck(self.lib.gp_comm_init(self.h, ctypes.cast(buf, ctypes.c_void_p), int(nranks), int(rank)), 'gp_comm_init')
+        self.has_comm = True
+
+    has_comm = False
+
+    def allreduce(self, which='stats'):
+        """statistics: pack -> RCCL all-reduce(sum) -> unpack; grads: all-reduce of the gradient sums.  Enqueued on the engine's stream."""
+        self._ck(self.lib.gp_allreduce(self.h, 0 if which == 'stats' else 1), 'gp_allreduce')
+
+    def comm_destroy(self):
+        self._ck(self.lib.gp_comm_destroy(self.h), 'gp_comm_destroy')
+        self.has_comm = False
+
     def combine(self, src, which='stats', op='add'):
         """dst (self) += src or dst = src for the packed statistics / gradient-sum buffers (same device)."""
         self._ck(self.lib.gp_buffer_combine(self.h, src.h, 0 if which == 'stats' else 1, 0 if op == 'add' else 1), 'gp_buffer_combine')

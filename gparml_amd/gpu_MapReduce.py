@@ -80,10 +80,45 @@ def _read_csv(path):
 
 
 # ------------------------------------------------------------------------------------------------- init
+def _streaming_pca(options, names):
+    """supporting_functions.PCA (supporting_functions.py:102-121: left singular vectors of the centred data, each scaled to unit standard
+    deviation) over ALL shards (local_MapReduce.py:54-65) without ever holding more than one shard: the reference concatenates every shard
+    on one host and takes a thin SVD of the whole matrix (64 GB at BASELINE configs[4]).  The same principal axes are the eigenvectors of the
+    D x D scatter matrix, which is a SUM over shards: pass 1 accumulates, per shard, the row count, the sum and the Gram matrix of the rows
+    shifted by a provisional centre (the first shard's mean: keeps the later correction for the true mean small against the scatter);
+    `eigh` of the D x D matrix gives the axes V and the variances lambda / N; pass 2 projects each shard, X_s = (Y_s - mean) V / sqrt(lambda / N).
+    Identical to the SVD form up to the sign of a component (fixed here: the largest entry of every axis is positive) and rounding
+    (tests/test_init_against_reference.py: 1e-9 against the reference's own files).  Returns the per-shard projection."""
+    Q = options['Q']
+    n_tot, shift, ssum, gram = 0, None, None, None
+    for name in names:
+        Y = _read_csv(options['input'] + '/' + name)
+        if shift is None:
+            shift = Y.mean(axis=0)
+            ssum, gram = numpy.zeros(Y.shape[1]), numpy.zeros((Y.shape[1], Y.shape[1]))
+        Yc = Y - shift
+        n_tot += Y.shape[0]
+        ssum += Yc.sum(axis=0)
+        gram += Yc.T.dot(Yc)
+    delta = ssum / n_tot                                            # true mean - provisional centre
+    scatter = gram - n_tot * numpy.outer(delta, delta)
+    lam, V = numpy.linalg.eigh(scatter)
+    order = numpy.argsort(lam)[::-1][:Q]
+    lam, V = lam[order], V[:, order]
+    V = V * numpy.sign(V[numpy.argmax(numpy.abs(V), axis=0), numpy.arange(V.shape[1])])[None, :]
+    mean, std = shift + delta, numpy.sqrt(lam / n_tot)              # X.std(axis=0) of the projected data (ddof = 0)
+
+    def project(name):
+        return (_read_csv(options['input'] + '/' + name) - mean).dot(V) / std
+
+    return project
+
+
 def init(options):
     """local_MapReduce.init (local_MapReduce.py:27-104): count the points; create embeddings / variances unless
     loading or using fixed embeddings.  The PCA / random initialisation is one-off host preprocessing (out of the hot
-    path); PPCA / FA initialisers of supporting_functions.py are not provided."""
+    path); PCA streams over the shards (_streaming_pca: per-shard D x D scatter sums + eigh) instead of concatenating all data on one
+    host; PPCA / FA initialisers of supporting_functions.py are not provided."""
     names = sorted(os.listdir(options['input'] + '/'))
     lengths = []
     for name in names:
@@ -92,19 +127,17 @@ def init(options):
     options['N'] = sum(lengths)
     if not options['fixed_embeddings'] and not options['load']:
         if options['init'] == 'PCA':
-            Y = numpy.concatenate([_read_csv(options['input'] + '/' + n) for n in names])
-            Yc = Y - Y.mean(axis=0)
-            U, s, Vt = numpy.linalg.svd(Yc, full_matrices=False)
-            X = Yc.dot(Vt[:options['Q']].T)
-            X = X / X.std(axis=0)
+            X = None
+            project = _streaming_pca(options, names)
         elif options['init'] == 'random':
             X = numpy.random.randn(options['N'], options['Q'])
+            project = None
         else:
             raise Exception("init '%s' is not provided by the GPU backend (PCA or random)" % options['init'])
         start = 0
         for name, n in zip(names, lengths):
             base = options['embeddings'] + '/' + name
-            save(base + '.embedding.npy', X[start:start + n])
+            save(base + '.embedding.npy', X[start:start + n] if project is None else project(name))
             v = numpy.clip(0.5 * numpy.ones((n, options['Q'])) + 0.01 * numpy.random.randn(n, options['Q']), 0.001, 1)
             save(base + '.variance.npy', numpy.log(numpy.exp(v) - 1.0))            # transformVar_back, :90-93
             start += n

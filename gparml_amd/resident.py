@@ -34,6 +34,7 @@ class ResidentModel(object):
         self.bounds = [(None, None)] * (M * Q) + [(0, None)] + [(0, None)] * Q + [(0, None)]
         self._pos = positive_mask(self.bounds)
         self._dev_tensors = None
+        self._native = None         # True once the root engine reduces through its own RCCL communicator (gp_allreduce)
 
     @staticmethod
     def _dist_ready():
@@ -60,17 +61,24 @@ class ResidentModel(object):
     def _allreduce_buffers(self, which):
         if self._dist is None:
             return
-        from .dist import device_tensor
+        from .dist import device_tensor, init_native_comm
         import torch
         root = self.engines[0]
+        if self._native is None:
+            self._native = init_native_comm(root, self._dist, self.group)
+        if self._native:
+            root.allreduce(which)             # gp_allreduce: RCCL on the engine's stream (statistics packed inside)
+            self.n_collectives += 1
+            return
+        if self._dev_tensors is None:         # zero-copy views of the two device buffers, made once (the pointers never change)
+            p, n = root.stats_packed_buffer()
+            g, m = root.grads_buffer()
+            dev = torch.device('cuda', root.device)
+            self._dev_tensors = {'stats': device_tensor(p, n, dev), 'grads': device_tensor(g, m, dev)}
         if which == 'stats':
             # across processes the statistics travel without padding and without Psi2's lower triangle (gp_stats_pack / gp_stats_unpack)
             root.stats_pack()
-            p, n = root.stats_packed_buffer()
-        else:
-            p, n = root.grads_buffer()
-        t = device_tensor(p, n, torch.device('cuda', root.device))
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        self._dist.all_reduce(self._dev_tensors[which], op=self._dist.ReduceOp.SUM, group=self.group)
         if which == 'stats':
             root.stats_unpack()
         self.n_collectives += 1

@@ -39,7 +39,8 @@ enum {
   GP_ERR_HIP = 4,          /* -> RuntimeError                                                               */
   GP_ERR_STATE = 5,        /* call sequence violated (e.g. phase2 before global_step) -> RuntimeError       */
   GP_ERR_UNSUPPORTED = 6,
-  GP_RETRY_JITTER = 7      /* a Cholesky factorisation failed for the first time: repeat the global step with gp_global_step_jitter */
+  GP_RETRY_JITTER = 7,     /* a Cholesky factorisation failed for the first time: repeat the global step with gp_global_step_jitter */
+  GP_ERR_RCCL = 8          /* RCCL missing (dlopen) or a collective failed -> RuntimeError                                        */
 };
 
 /* what gp_download can fetch (every array the reference exposes on the path) */
@@ -116,6 +117,19 @@ int gp_buffer_combine(gp_ctx* dst, const gp_ctx* src, int which, int op);
  * gp_phase2; they are the contracted form of the reference's sum_d_*_d_Z / d_alpha statistics). */
 int gp_scale_buffer(gp_ctx* ctx, int which, double factor);
 int gp_scale_stats(gp_ctx* ctx, double factor);   /* = gp_scale_buffer(ctx, 0, factor) */
+/* ---- the reduce across GPUs inside the library (`allreduce(ctx, phase)`) ------------------------
+ * statistics_reducer (local_MapReduce.py:250-277) as an RCCL all-reduce(sum, float64) on the context's stream, one rank per GPU.
+ * RCCL is resolved with dlopen at the first of these calls (GP_ERR_RCCL if it cannot be found; GPARML_RCCL_LIB names a specific
+ * library), so a single-GPU user never needs it.  Rank 0 obtains the 128-byte ncclUniqueId with gp_comm_unique_id and distributes it;
+ * every rank then calls gp_comm_init(ctx, id, nranks, rank) (collective: all ranks must call it).  gp_allreduce(ctx, 0) packs the
+ * statistics (gp_stats_pack), all-reduces the packed buffer and unpacks it -- call it between gp_phase1 (and any drop-out scaling)
+ * and gp_global_step; gp_allreduce(ctx, 1) all-reduces the gradient sums between gp_phase2 and gp_finish.  Nothing synchronises
+ * the host.  A host that prefers its own communicator all-reduces gp_stats_packed_buffer / gp_grads_buffer itself. */
+#define GP_COMM_ID_BYTES 128
+int gp_comm_unique_id(void* id_out_128_bytes);
+int gp_comm_init(gp_ctx* ctx, const void* unique_id_128_bytes, int nranks, int rank);
+int gp_allreduce(gp_ctx* ctx, int which);
+int gp_comm_destroy(gp_ctx* ctx);
 /* calculate_global_statistics + Kmm parts of calculate_global_derivatives (parallel_GPLVM.py:302-369):
  * Kmm, Cholesky of Kmm and Kmm+beta*Psi2, F, dF_d*, grad_beta.  Asynchronous: the launches are enqueued and nothing is
  * read back; the outcome is reported by the first of gp_global_status / gp_finish / gp_download that follows (one host
@@ -190,6 +204,10 @@ int gp_debug_gemm(int device, int ta, int tb, int m, int n, int k, double alpha,
                   double beta, double* C);
 /* make gp_buffer_combine take its cross-device path (peer copy through the staging buffer) even on one device */
 int gp_debug_force_staging(int on);
+/* process-wide switches of the global step's extended-precision pieces (both on by default): "dd_kipsi2" -- K_mm^-1 Psi2 accumulated in
+ * double-double (the product whose float64 rounding is grad_Z's whole error at cond ~1e10), "refine_E" -- one refinement
+ * step of E with a double-double residual.  bench.py times the global step with and without to print their cost. */
+int gp_debug_set_option(const char* name, int value);
 /* in-place lower Cholesky + inverse of an SPD (n,n) matrix; logdet out; returns GP_ERR_NOT_PD on failure */
 int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet);
 

@@ -24,6 +24,17 @@ MODS = ['kernels', 'kernel_exp', 'partial_terms', 'nputil', 'supporting_function
         'scg_adapted_local_MapReduce', 'scg_adapted', 'gd_local_MapReduce', 'gd', 'parallel_GPLVM']
 
 
+# in-memory source substitutions on top of lib2to3 (python-2 semantics it cannot see): numpy '== None' tests, integer '/' in slice bounds
+PATCHES = {'kernels': [('if ard==None:', 'if ard is None:'), ('if X2==None:', 'if X2 is None:')],
+           'predict': [('len(flat_array_transformed)/2', 'len(flat_array_transformed)//2'), ('if mask == None:', 'if mask is None:')]}
+
+
+def _patched(name, src):
+    for old, new in PATCHES.get(name, ()):
+        src = src.replace(old, new)
+    return src
+
+
 def load_reference():
     warnings.filterwarnings('ignore')
     from lib2to3.refactor import RefactoringTool, get_fixers_from_package
@@ -36,18 +47,14 @@ def load_reference():
     tool = RefactoringTool(get_fixers_from_package('lib2to3.fixes'))
     mods = {}
     for name in MODS:
-        src = open(os.path.join(REF, name + '.py')).read()
-        if name == 'kernels':
-            src = src.replace('if ard==None:', 'if ard is None:').replace('if X2==None:', 'if X2 is None:')
+        src = _patched(name, open(os.path.join(REF, name + '.py')).read())
         src = str(tool.refactor_string(src + '\n', name))
         mod = types.ModuleType(name)
         mod.__file__ = os.path.join(REF, name + '.py')
         sys.modules[name] = mod
         mods[name] = mod
     for name in MODS:                       # exec after all are registered so intra-reference imports resolve
-        src = open(os.path.join(REF, name + '.py')).read()
-        if name == 'kernels':
-            src = src.replace('if ard==None:', 'if ard is None:').replace('if X2==None:', 'if X2 is None:')
+        src = _patched(name, open(os.path.join(REF, name + '.py')).read())
         src = str(tool.refactor_string(src + '\n', name))
         if name == 'nputil':
             src = src.replace("np.seterr(all='raise')", "pass")

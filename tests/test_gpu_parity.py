@@ -213,6 +213,7 @@ eng = ShardEngine(N, D, M, Q)
 eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
 eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
 ev = DistributedEvaluator(eng, device=torch.device('cuda', 0), force_collectives=True)
+assert ev.native == (os.environ.get('GPARML_NATIVE_ALLREDUCE', '1') != '0'), ev.native     # gp_allreduce inside the library unless switched off
 out = ev.evaluate(False)
 st, gt = ev._tensors()
 assert st.is_cuda and st.dtype == torch.float64 and st.data_ptr() == eng.stats_packed_buffer()[0] and gt.data_ptr() == eng.grads_buffer()[0]
@@ -225,11 +226,52 @@ print('RCCL_OK')
 """
 
 
-def test_rccl_allreduce_on_the_packed_device_buffers():
+@pytest.mark.parametrize('native', ['1', '0'])
+def test_rccl_allreduce_on_the_packed_device_buffers(native):
     """The N>1 path on one GPU, in a fresh process: a 1-rank RCCL group all-reduces the engine's packed device buffers
-    in place (zero-copy torch view of the library's memory) and the evaluation still matches the oracle."""
+    in place and the evaluation still matches the oracle -- through the library's own communicator (gp_comm_init / gp_allreduce, native = 1)
+    and through torch.distributed on a zero-copy view of the library's memory (native = 0)."""
+    import os
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, '-c', RCCL_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, '-c', RCCL_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GPARML_NATIVE_ALLREDUCE=native))
     assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+NATIVE_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+N, D, M, Q = 700, 5, 33, 3
+d = Fz.synthetic_shard(N, D, M, Q, regime='B', seed=5, zseed=6, alpha_value=0.4)
+eng = ShardEngine(N, D, M, Q)
+eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+plain = eng.evaluate(True)
+try:
+    eng.allreduce('stats')
+    raise SystemExit('gp_allreduce without a communicator did not fail')
+except RuntimeError as e:
+    assert 'gp_comm_init' in str(e), e
+eng.comm_init(ShardEngine.comm_unique_id(), 1, 0)          # what a C consumer does: no torch in this process
+eng.phase1(); eng.allreduce('stats'); eng.global_step(sync=False); eng.phase2(True); eng.allreduce('grads')
+out = eng.finish()
+assert out['F'] == plain['F'] and np.array_equal(out['grad_Z'], plain['grad_Z']) and np.array_equal(out['grad_alpha'], plain['grad_alpha'])
+eng.comm_destroy(); eng.close()
+assert 'torch' not in sys.modules
+print('NATIVE_OK')
+"""
+
+
+def test_library_allreduce_without_torch():
+    """gp_comm_unique_id / gp_comm_init / gp_allreduce (RCCL resolved by dlopen inside the library) in a process that never imports torch: a
+    one-rank communicator leaves the evaluation bit-identical; gp_allreduce before gp_comm_init is a state error."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, '-c', NATIVE_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'NATIVE_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -40,3 +40,37 @@ def test_predict_callback_matches_oracle():
     # and a short optimisation decreases the objective
     res = p.test(Yt, Xm, Xs, iterations=3)
     assert -res[2] <= f + 1e-9
+
+
+def _replay_reference_fixture(make_callback):
+    """The reference's own predict.test runs (tests/golden/make_predict_golden.py: a model trained by parallel_GPLVM.main, then
+    predict.likelihood_and_gradient called by its SCG; run A = three new points from nearest-neighbour means, run B = one point from a random
+    inducing point with a restart): every recorded call is replayed -- same flat vector in, objective 1e-6 and gradient 1e-5 out."""
+    import os
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'predict_gplvm_2shards.npz'))
+    gs = dict(Z=z['global_Z'], sf2=z['global_sf2'], alpha=z['global_alpha'], beta=z['global_beta'])
+    acc = {k: z['acc_' + k] for k in ('sum_YYT', 'sum_exp_K_mi_K_im', 'sum_exp_K_miY', 'sum_exp_K_ii', 'sum_KL')}
+    Q = int(z['Q'])
+    n = 0
+    for tag in ('A', 'B'):
+        Yt = z[tag + '_Y_test']
+        cb = make_callback(gs, acc, int(z['N']), int(z['D']), Yt, (Yt.shape[0], Q))
+        for k in range(int(z[tag + '_n_calls'])):
+            f, g = cb(z['%s_call%d_x' % (tag, k)])
+            assert_close(f, z['%s_call%d_f' % (tag, k)], 1e-6, what='run %s call %d: objective' % (tag, k))
+            assert_close(g, z['%s_call%d_g' % (tag, k)], 1e-5, what='run %s call %d: gradient' % (tag, k))
+            n += 1
+    assert n == 21
+
+
+def test_predict_callback_replays_the_reference_runs():
+    from gparml_amd.predict import Predictor
+
+    def make(gs, acc, N, D, Yt, shape):
+        p = Predictor(gs, acc, N, D)
+        p.Y_test, p.shape = Yt, shape
+        p.bounds = [(None, None)] * (shape[0] * shape[1]) + [(0, None)] * (shape[0] * shape[1])
+        return p.likelihood_and_gradient
+
+    _replay_reference_fixture(make)

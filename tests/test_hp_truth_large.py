@@ -1,22 +1,20 @@
 """Parity at the benchmark's own workload and FULL size (BASELINE configs[2]: N=1e6, D=100, M=512, Q=10, alpha=0.1, beta=10,
-bench.py's generator, seed 100) against an extended-precision truth.
+bench.py's generator) against an extended-precision truth, on FIVE data / inducing-point draws at N = 1e5 and N = 1e6.
 
 tests/golden/make_hp_truth_large.py -> oracle/hp_truth.c evaluates the workload in x87 80-bit long double end to end (its own
-uncertainty, measured by re-running the global step on the reversed order of the inducing points: 1.4e-8 on grad_Z) and stores
-the truth with the errors of the two float64 CPU arrangements:
+uncertainty, measured by re-running the global step on the reversed order of the inducing points: 0.7e-8 .. 2.6e-8 on grad_Z) and stores
+the truth with the errors of the two float64 CPU arrangements.  cond(Kmm + beta Psi2) is 1.4e10 .. 3.1e10 over the draws, and on EVERY draw
+both float64 CPU arrangements are outside the 1e-5 contract on grad_Z: the reference's LU arrangement by 3.2e-5 .. 8.9e-5, the Cholesky
+port by 1.4e-5 .. 4.3e-5.  The device's round-3 global step (float64 + one refinement step of E) was 5.7e-6 .. 2.1e-5: inside the contract on
+the benchmark's own draw, OUTSIDE it on draw (102, 12) at both sizes (profiles/r04_seed_floor_N1e5.txt, _N1e6.txt).
 
-    N = 1e5: cond(Kmm + beta Psi2) = 1.37e10   float64 LU (the reference's arrangement) 5.3e-5, float64 Cholesky port 1.6e-5 on grad_Z
-    N = 1e6: cond(Kmm + beta Psi2) = 1.41e10   float64 LU 8.9e-5,                      float64 Cholesky port 2.3e-5 on grad_Z
+Round 4 located the error: it is the float64 ACCUMULATION of one product of the global step, G = Kmm^-1 Psi2 (entries of both signs around
+1e5 times entries around N, the result a small difference).  With that product accumulated in double-double (csrc/linalg.hip,
+ddacc_gemm_kernel; inputs and output float64; +0.05 ms) the device is 1e-8 .. 1e-7 from the truth on grad_Z -- the truth's own uncertainty --
+on every draw and at both sizes.  The device path is held to
 
-i.e. NO float64 evaluation of this bound certifies grad_Z to 1e-5 at this conditioning: with the long-double partials rounded to
-double the float64 phase 2 reproduces grad_Z to 1.9e-10, so the whole error is the M x M global step, and even a long-double
-global step on double-rounded statistics is left with 6e-9 on dF/dPsi2, which grad_Z (a ~1000-fold amplification through the
-K_mm part) turns into ~1e-6..1e-5.  The device's global step refines E = (K_mm + beta Psi2)^-1 Psi1^T Y once with a
-double-double residual (csrc/linalg.hip, solve_residual_kernel), which takes its grad_Z from 3.7e-5 / 1.3e-5 to 1.07e-5 / 7.5e-6 (N = 1e5 / 1e6).
-The device path is held to
-
-    err(GPU, truth) <= max(1e-5, best float64 CPU arrangement's error)    per gradient block, relative to the block's largest magnitude
-    err(GPU, truth) <= 1e-5 on every block at the full size N = 1e6 (the headline configuration)
+    err(GPU, truth) <= 1e-5   on every gradient block, every draw, both sizes (BASELINE.json's contract; relative to the block's largest magnitude)
+    err(GPU, truth) <= 5e-7   on grad_Z (regression guard: what the double-double product delivers, with a margin over the truth's uncertainty)
     |F_gpu - F_truth| <= 1e-9 |F_truth|
 """
 import os
@@ -81,11 +79,12 @@ def test_float64_cpu_paths_against_the_truth_1e5():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N', [100000, 1000000])
-def test_gpu_against_the_long_double_truth(N):
-    """The benchmark's kernel sequence (fixed embeddings: p1v2_kernel -> global step -> p2_fast8_kernel<3>) on the benchmark's own
-    inputs, at N = 1e5 and at the full N = 1e6."""
+@pytest.mark.parametrize('seed,z_seed', DRAWS)
+def test_gpu_against_the_long_double_truth(N, seed, z_seed):
+    """The benchmark's kernel sequence (fixed embeddings: p1v2_kernel -> global step -> p2_fast8_kernel<3>) on five draws of the benchmark's
+    workload, at N = 1e5 and at the full N = 1e6.  No escape clause: 1e-5 on every block."""
     from gparml_amd.engine import ShardEngine
-    z = _fixture(N)
+    z = _fixture(N, seed, z_seed)
     d, (N, D, M, Q) = _inputs(z)
     eng = ShardEngine(N, D, M, Q)
     eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
@@ -94,8 +93,32 @@ def test_gpu_against_the_long_double_truth(N):
     eng.close()
     assert abs(out['F'] - float(z['truth_F'])) <= 1e-9 * abs(float(z['truth_F']))
     rep = {k: (_err(out[k], z['truth_' + k]), float(z['err_lu_' + k]), float(z['err_chol_' + k])) for k in BLOCKS}
-    print('N=%d error vs truth (gpu, float64 LU, float64 Cholesky):' % N, {k: '%.2e %.2e %.2e' % v for k, v in rep.items()})
+    print('N=%d draw (%s, %s) cond %.2e error vs truth (gpu, float64 LU, float64 Cholesky):' % (N, seed, z_seed, float(z['cond_A'])),
+          {k: '%.2e %.2e %.2e' % v for k, v in rep.items()})
     for k in BLOCKS:
-        assert rep[k][0] <= max(1e-5, min(rep[k][1], rep[k][2])), (k, rep[k])
-        if N == 1000000:
-            assert rep[k][0] <= 1e-5, (k, rep[k])
+        assert rep[k][0] <= 1e-5, (k, rep[k])
+    assert rep['grad_Z'][0] <= 5e-7, rep['grad_Z']
+
+
+@pytest.mark.gpu
+def test_the_double_double_product_is_what_closes_the_gap():
+    """The same evaluation with the round-3 global step (gp_debug_set_option('dd_kipsi2', 0): K_mm^-1 Psi2 on the float64 matrix core) on the
+    draw where it fails the contract: 1.4e-5 at N = 1e5 (2.1e-5 at N = 1e6), against < 5e-7 with the double-double accumulation."""
+    from gparml_amd import _lib
+    from gparml_amd.engine import ShardEngine
+    z = _fixture(100000, 102, 12)
+    d, (N, D, M, Q) = _inputs(z)
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    lib = _lib.load()
+    try:
+        assert lib.gp_debug_set_option(b'dd_kipsi2', 0) == 0
+        plain = _err(eng.evaluate(False)['grad_Z'], z['truth_grad_Z'])
+    finally:
+        assert lib.gp_debug_set_option(b'dd_kipsi2', 1) == 0
+    dd = _err(eng.evaluate(False)['grad_Z'], z['truth_grad_Z'])
+    eng.close()
+    print('draw (102, 12), N = 1e5: grad_Z vs truth  float64 product %.2e   double-double product %.2e' % (plain, dd))
+    assert plain > 5e-6 and dd <= 5e-7 and dd < plain / 10
+    assert lib.gp_debug_set_option(b'no_such_option', 1) == _lib.GP_ERR_BAD_ARG

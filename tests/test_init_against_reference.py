@@ -66,3 +66,27 @@ def test_pca_embeddings_variances_and_initial_vector(name, tmp_path, monkeypatch
         matched = order
         break
     assert matched is not None, 'no shard order reproduces the reference variances'
+
+
+def test_streaming_pca_equals_the_svd_of_all_data(tmp_path):
+    """gpu_MapReduce._streaming_pca (per-shard scatter sums + eigh, one shard in memory at a time) against supporting_functions.PCA's
+    arithmetic on the concatenated data (thin SVD of the centred matrix, left singular vectors scaled to unit standard deviation,
+    supporting_functions.py:102-121): three ragged shards with a large common offset, D = 40, Q = 5."""
+    from gparml_amd import gpu_MapReduce as mr
+    rs = np.random.RandomState(8)
+    D, Q = 40, 5
+    W = rs.randn(7, D) * np.array([5, 4, 3, 2, 1.5, 0.3, 0.2])[:, None]
+    shards = [rs.randn(n, 7).dot(W) + 0.05 * rs.randn(n, D) + 100.0 for n in (57, 130, 21)]
+    os.makedirs(str(tmp_path / 'input'))
+    names = ['s%d' % i for i in range(3)]
+    for n, Y in zip(names, shards):
+        np.savetxt(str(tmp_path / 'input' / n), Y, delimiter=',', fmt='%.17g')
+    project = mr._streaming_pca({'input': str(tmp_path / 'input'), 'Q': Q}, names)
+    X = np.concatenate([project(n) for n in names])
+    Y = np.concatenate(shards)
+    U = np.linalg.svd(Y - Y.mean(axis=0), full_matrices=False)[0][:, :Q]
+    U = U / U.std(axis=0)
+    for q in range(Q):
+        s = np.sign(np.dot(X[:, q], U[:, q]))
+        assert np.max(np.abs(s * X[:, q] - U[:, q])) <= 1e-9 * np.max(np.abs(U[:, q])), q
+    np.testing.assert_allclose(X.std(axis=0), 1.0, rtol=1e-12)

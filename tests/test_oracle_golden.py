@@ -78,3 +78,31 @@ def test_softplus_transforms():
     assert np.allclose(L.transformVar_back(y), x, rtol=1e-9, atol=1e-9)
     h = 1e-6
     assert np.allclose((L.transformVar(x + h) - L.transformVar(x - h)) / (2 * h), L.transformVar_grad(x), atol=1e-8)
+
+
+def test_literal_oracle_replays_the_reference_predict_runs():
+    """predict.likelihood_and_gradient (predict.py:116-144) as the reference ran it (tests/golden/make_predict_golden.py) on the literal
+    restatement of partial_terms: the sequence tests/test_gpu_predict.py holds the GPU class to."""
+    import os
+    from conftest import GOLDEN_DIR
+    from oracle import literal as L
+    z = np.load(os.path.join(GOLDEN_DIR, 'predict_gplvm_2shards.npz'))
+    M, Q, N, D = int(z['M']), int(z['Q']), int(z['N']), int(z['D'])
+    acc = {k: z['acc_' + k] for k in ('sum_YYT', 'sum_exp_K_mi_K_im', 'sum_exp_K_miY', 'sum_exp_K_ii', 'sum_KL')}
+    for tag in ('A', 'B'):
+        Yt = z[tag + '_Y_test']
+        n = Yt.shape[0] * Q
+        for k in range(int(z[tag + '_n_calls'])):
+            x = z['%s_call%d_x' % (tag, k)]
+            Xm, Xs = x[:n].reshape(-1, Q), np.log1p(np.exp(x[n:])).reshape(-1, Q)
+            o = L.PartialTermsOracle(z['global_Z'], float(z['global_sf2'].reshape(-1)[0]), z['global_alpha'].reshape(-1),
+                                     float(z['global_beta'].reshape(-1)[0]), M, Q, N, D)
+            o.set_data(Yt, Xm, Xs, True)
+            new = o.get_local_statistics()
+            o.set_local_statistics(acc['sum_YYT'] + new['sum_YYT'], acc['sum_exp_K_mi_K_im'] + new['sum_exp_K_mi_K_im'],
+                                   acc['sum_exp_K_miY'] + new['exp_K_miY'], acc['sum_exp_K_ii'] + new['sum_exp_K_ii'], acc['sum_KL'] + new['KL'])
+            f = -o.logmarglik()
+            g = -np.concatenate((o.grad_X_mu().flatten(), o.grad_X_S().flatten() / (1.0 + np.exp(-x[n:]))))
+            assert abs(f - float(z['%s_call%d_f' % (tag, k)])) <= 1e-9 * abs(f)
+            gr = z['%s_call%d_g' % (tag, k)]
+            assert np.max(np.abs(g - gr)) <= 1e-8 * np.max(np.abs(gr))

@@ -176,6 +176,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (c->bmap) (void)hipFree(c->bmap);
   if (c->staging) (void)hipFree(c->staging);
   gp::p1v2_free(c);
+  gp::p1i8_free(c);
   gp::comm_free(c);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 4; ++i) if (c->gev[i]) (void)hipEventDestroy(c->gev[i]);
@@ -256,6 +257,7 @@ extern "C" int gp_upload_shard(gp_ctx* c, const double* Y, const double* X_mu, c
   c->have_data = true;
   c->have_dir = false;
   c->prep_fixa_valid = false;
+  c->i8_y_valid = false;
   return GP_OK;
 }
 

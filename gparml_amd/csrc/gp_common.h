@@ -11,6 +11,10 @@
 
 namespace gp {
 
+#ifndef GP_I8_DIGITS
+#define GP_I8_DIGITS 6     // signed 7-bit digits per operand of the int8 phase-1 prototype (p1i8.hip): 42 bits below the operand's scale
+#endif
+
 inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 // latent width of the packed per-point records of psi1_kernel (Q <= 16: Q rounded up to 2) / psi1_wide_kernel (24, 32, 52, 64); 0: none
 inline int psi1_qp(int Q) { return Q <= 16 ? (Q + 1) / 2 * 2 : Q <= 24 ? 24 : Q <= 32 ? 32 : Q <= 52 ? 52 : Q <= 64 ? 64 : 0; }
@@ -88,6 +92,10 @@ struct gp_ctx {
   int* tiles = nullptr;       // phase-1 tile table (int2)
   int n_tiles = 0, p1_slices = 0, p1_cps = 0;
   void* p1plan = nullptr;     // regime-A phase-1 plan (job and output tables of p1v2.hip), built on first use
+  void* i8plan = nullptr;     // int8 phase 1 (p1i8.hip): digit buffers, job tables; built on first use
+  bool i8_active = false;     // this evaluation's phase 1 runs on the int8 matrix core (psi1_kernel wrote the digits)
+  bool i8_y_valid = false;    // Y's digits are current (reset by gp_upload_shard)
+  bool i8_unsupported = false;  // the int8 plan could not be built for this context (falls back to the float64 kernels)
   int* bmap = nullptr;        // phase-1 block -> (slice, tile type) placement table
   int bmap_T = -1, bmap_S = -1, bmap_blocks = 0;
   double* klpart = nullptr;   // [blocks] partial KL sums
@@ -189,6 +197,12 @@ int run_upload_y(gp_ctx* c, const double* dY);
 int run_prep_and_generate(gp_ctx* c);
 int run_phase1(gp_ctx* c);
 int run_phase2(gp_ctx* c);
+bool p2_fast_mode(const gp_ctx* c);
+// p1i8.hip (regime A phase 1 on the int8 matrix core)
+bool p1i8_applicable(const gp_ctx* c);
+int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ);
+int run_phase1_i8(gp_ctx* c);
+void p1i8_free(gp_ctx* c);
 // p1v2.hip (regime A phase 1 without wasted tile slots)
 bool p1v2_applicable(const gp_ctx* c);
 int run_phase1_v2(gp_ctx* c);

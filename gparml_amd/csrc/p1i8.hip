@@ -1,0 +1,343 @@
+// Phase 1 of the fixed-embedding path on the INT8 matrix core -- the prototype behind VERDICT r03 item 6 (Ozaki-style FP64 on int8), OFF by
+// default (GPARML_P1_I8=1 or gp_debug_set_option("p1_i8", 1) switches it on; DESIGN.md section 6 has the gate's numbers and its outcome):
+//   [Psi2 | C] = K^T [K | Y]   (partial_terms.py:45-52, 79-80; kernel_exp.py:13-49)
+// with the float64 operands split into signed 7-bit digits,
+//   x = scale * sum_{j=1..S} d_j 128^-j,   d_j in [-64, 64],  |x| <= scale / 2,   S = 6 (42 bits below the operand's scale)
+//   x y = scale_x scale_y sum_{a,b} d_a e_b 128^-(a+b),  digit products with a + b <= L = 8 kept (26 of 36),
+// each an EXACT integer matrix product on v_mfma_i32_32x32x32_i8 (4.6 POPS measured, 58x the FP64 rate: profiles/r04_i8_ubench.txt);
+// products of equal order a + b share one int32 accumulator.  |d e| <= 4096 and at most S pairs per order, so an accumulator holds
+// 2^31 / (6 * 4096) = 87381 rows: one slice of the shard per workgroup, converted to float64 once at the end.  Integer sums do not depend on
+// the order of accumulation: the digit products are bit-identical for any slicing of the shard.
+//
+// What the gate found (exact CPU emulation of this arithmetic, tests/devtools, and the kernel itself -- they agree to the digit):
+//   * which products are dropped matters more than how many digits are kept.  Psi1's entries span ten decades inside a column and their
+//     density falls with magnitude, so inside a digit cell the remainder has a negative mean: neighbouring digits of ONE number are
+//     correlated, and dropping their cross products biases the DIAGONAL of Psi2 (+1e-12 relative with S = 5 / L = 6, 15 products) -- a jitter
+//     on K_mm + beta Psi2 (cond 1e10) that moves grad_Z by 1.2e-5 .. 1.7e-5 from the 80-bit truth at N = 1e6 (measured): outside the contract.
+//     S = 6 / L = 7 (21 products): 3.65e-6 (emulation and kernel, identical).  S = 6 / L = 8 (26 products): bias 2e-16, Psi2 good to
+//     3.5e-15, grad_Z 1.6e-8 -- indistinguishable from float64 statistics.  That is the configuration built here.
+//   * the kernel below reaches ~46 % of the int8 MFMA rate (every LDS-DMA instruction costs its SIMD ~60 cycles of MFMA issue and the panels
+//     are 40 KB per k-step); at that rate 26 products take as long as the float64 p1v2_kernel (5.9 ms at N = 1e6), and psi1_kernel pays
+//     +0.45 ms for writing the digits.  So the float64 matrix core stays in charge; the projected 1.3x is not there.
+//
+// Digits live in HBM as Sl[j][n / 16][col][16]: the 16 consecutive rows a lane feeds to the matrix core as ONE 16-byte operand, columns =
+// the Mp columns of Psi1 followed by the Dp columns of Y (the layout of Kaug's rows).  Psi1's digits are written by psi1_kernel while it
+// generates Psi1 (psi.hip: each lane already walks 16 rows of its two columns), Y's once per upload.  3.8 GB at N = 1e6, M = 512, D = 100.
+//
+// Kernel: one workgroup = one 128 x 128 output tile x one n-slice, 8 waves as 2 x 4 of 64 x 32 (two 32 x 32 MFMA tiles, L - 1 orders), k-step =
+// 32 rows; both operand panels (S digits x 2 row blocks x 128 columns x 16 B) arrive by LDS-DMA straight in operand order (the digit
+// layout IS the LDS image: no swizzle, no padding) through a three-stage ring.
+#include "gp_common.h"
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace gp {
+
+constexpr int I8S = GP_I8_DIGITS;          // digits per operand (gp_common.h)
+constexpr long I8_MAX_ROWS = 81920;        // rows per workgroup slice (int32 accumulators: 2^31 / (6 * 4096) = 87381)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+std::atomic<int> g_opt_p1_i8{[] { const char* e = getenv("GPARML_P1_I8"); return (e && e[0] == '1') ? 1 : 0; }()};   // off unless asked for
+constexpr int I8L = 8;                     // digit products with a + b <= I8L (digits numbered from 1) are kept
+constexpr int I8O = I8L - 1;               // accumulators: orders a + b = 2 .. I8L
+
+struct I8Job { int ci, cj; int ks0, ks1; int part; int pad0, pad1, pad2; };   // column blocks (128 combined columns), k-steps [ks0, ks1) of 32 rows; ci < 0: idle
+struct I8Args { const int8_t* Sl; long strideJ; int LDK; const I8Job* jobs; double* part; };
+
+constexpr int I8_PANEL = I8S * 2 * 128 * 16;          // bytes of one operand panel of one k-step: [digit][row block of 16][128 columns][16 B]
+constexpr int I8_STAGE = 2 * I8_PANEL;                // A panel | B panel
+constexpr int I8_STAGES = 3;
+
+// Workgroup = one 128 x 128 output tile x one n-slice; 8 waves as 2 x 4, wave tile 64 x 32 = two 32x32 MFMA tiles: 32 accumulators per order.
+// Three-stage LDS ring, one barrier per k-step: the DMA of k-step i + 2 is issued before the MFMAs of k-step i (two k-steps = ~4k cycles cover
+// an HBM round trip; with a two-stage ring the kernel ran at 45 % of the MFMA rate).
+__global__ void __launch_bounds__(512, 1) p1i8_kernel(I8Args a) {
+  extern __shared__ __attribute__((aligned(16))) int8_t i8lds[];     // [3 stages][A panel | B panel]
+  const I8Job job = a.jobs[blockIdx.x];
+  if (job.ci < 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const bool diag = job.ci == job.cj;
+  v16i acc[I8O][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+      for (int o = 0; o < I8O; ++o) acc[o][t][i] = 0;
+    }
+  // LDS-DMA of one k-step: 4 I8S instructions of 1 KB per panel (a diagonal tile's B panel is its A panel), spread over the eight waves.
+  // Every wave issues the same number per k-step, so `s_waitcnt vmcnt(that number)` means "all but the newest k-step's have landed".
+  constexpr int NDMA_OFF = 8 * I8S / 8, NDMA_DIAG = (4 * I8S + 7) / 8;
+  auto dma = [&](int ks, int stage) {
+    const int ne = diag ? 4 * I8S : 8 * I8S;
+    for (int e = wave; e < (diag ? 8 * NDMA_DIAG : 8 * NDMA_OFF); e += 8) {
+      const int ee = e < ne ? e : ne - 1;                 // padding slots repeat the last transfer (same data, same place)
+      const int op = ee / (4 * I8S), rem = ee - op * (4 * I8S), j = rem >> 2, h = (rem >> 1) & 1, half = rem & 1;
+      const int col = (op ? job.cj : job.ci) * 128 + 64 * half + lane;
+      const int8_t* src = a.Sl + (long)j * a.strideJ + (((long)(2 * ks + h)) * a.LDK + col) * 16;
+      int8_t* dst = i8lds + stage * I8_STAGE + op * I8_PANEL + ((j * 2 + h) * 128 + 64 * half) * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+    }
+  };
+  const int kg = lane >> 5, r32 = lane & 31;
+  const int nks = job.ks1 - job.ks0;
+  dma(job.ks0, 0);
+  if (nks > 1) dma(job.ks0 + 1, 1);
+  for (int i = 0; i < nks; ++i) {
+    const int stage = i % I8_STAGES;
+    if (i + 1 < nks) { if (diag) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_DIAG) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_OFF) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage i has landed for every wave; stage (i + 2) % 3 = (i - 1) % 3 is no longer being read.  A raw barrier: __syncthreads() also waits
+    // for vmcnt(0), i.e. for the DMA of k-step i + 1 -- the ring would be one stage deep
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + 2 < nks) dma(job.ks0 + i + 2, (i + 2) % I8_STAGES);
+    const int8_t* pa = i8lds + stage * I8_STAGE;
+    const int8_t* pb = diag ? pa : pa + I8_PANEL;
+    v4i bv[I8S];
+#pragma unroll
+    for (int b = 0; b < I8S; ++b) bv[b] = *(const v4i*)(pb + ((b * 2 + kg) * 128 + wc * 32 + r32) * 16);
+#pragma unroll
+    for (int av_ = 0; av_ < I8S; ++av_) {
+      v4i av[2];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) av[ti] = *(const v4i*)(pa + ((av_ * 2 + kg) * 128 + wr * 64 + ti * 32 + r32) * 16);
+#pragma unroll
+      for (int b = 0; b < I8S; ++b)
+        if (b + av_ < I8O) {
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti)
+            acc[av_ + b][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ti], bv[b], acc[av_ + b][ti], 0, 0, 0);
+        }
+    }
+  }
+  // int32 -> float64: sum_o acc[o] 128^-(o + 2) (digit j has weight 128^-j, j = 1 .. S); C/D map of the 32x32 MFMA: col = lane & 31,
+  // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  double* out = a.part + (long)job.part * (TILE * TILE);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double v = 0.0, w = 1.0 / (128.0 * 128.0);
+      double ws[I8O];
+#pragma unroll
+      for (int o = 0; o < I8O; ++o) { ws[o] = w; w *= 1.0 / 128.0; }
+#pragma unroll
+      for (int o = I8O - 1; o >= 0; --o) v = fma((double)acc[o][ti][i], ws[o], v);     // small terms first
+      const int row = wr * 64 + ti * 32 + (i & 3) + 8 * (i >> 2) + 4 * kg, col = wc * 32 + r32;
+      out[row * TILE + col] = v;
+    }
+}
+
+// sum the slices' partial tiles in a fixed order, apply the operands' scales and write the statistics (both triangles of Psi2)
+struct I8Out { int ci, cj, first, nslices, stride, isC, pad0, pad1; };
+__global__ void __launch_bounds__(256) p1i8_reduce_kernel(const double* __restrict__ part, const I8Out* __restrict__ outs, const double* __restrict__ yscale,
+                                                          double kscale2, double kscale, double* __restrict__ Psi2, double* __restrict__ C, int Mp, int Dp) {
+  const I8Out o = outs[blockIdx.y];
+  const int e = blockIdx.x * 256 + threadIdx.x, r = e >> 7, c = e & 127;
+  const double* src = part + (long)o.first * (TILE * TILE) + e;
+  const long step = (long)o.stride * (TILE * TILE);
+  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int sl = 0;
+  for (; sl + 8 <= o.nslices; sl += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += src[(long)(sl + u) * step];
+  }
+  for (int u = 0; sl < o.nslices; ++sl, ++u) acc[u] += src[(long)sl * step];
+  const double s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  if (o.isC) {
+    const int d = (o.cj - Mp / TILE) * TILE + c;
+    if (d < Dp) C[((long)o.ci * TILE + r) * Dp + d] = s * kscale * yscale[d];
+  } else {
+    const long R = (long)o.ci * TILE + r, Cc = (long)o.cj * TILE + c;
+    Psi2[R * Mp + Cc] = s * kscale2;
+    if (o.ci != o.cj) Psi2[Cc * Mp + R] = s * kscale2;     // a diagonal tile is computed whole: integer sums, exactly symmetric
+  }
+}
+
+// ---- digits of Y (once per upload): per-column scale 2^e with max |y| <= 2^(e-1)
+__global__ void __launch_bounds__(256) i8_colmax_kernel(const double* __restrict__ Kaug, long ld, long Np, int Mp, int Dp, double* __restrict__ pmax /*[blocks][Dp]*/) {
+  const int d = threadIdx.x & 127, sub = threadIdx.x >> 7;
+  __shared__ double red[256];
+  for (int d0 = 0; d0 < Dp; d0 += 128) {
+    double m = 0.0;
+    for (long n = blockIdx.x * 2L + sub; n < Np; n += gridDim.x * 2L) m = fmax(m, fabs(Kaug[n * ld + Mp + d0 + d]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    if (sub == 0) pmax[(long)blockIdx.x * Dp + d0 + d] = fmax(red[d], red[128 + d]);
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) i8_yscale_kernel(const double* __restrict__ pmax, int blocks, int Dp, double* __restrict__ yscale) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= Dp) return;
+  double m = 0.0;
+  for (int b = 0; b < blocks; ++b) m = fmax(m, pmax[(long)b * Dp + d]);
+  int e = 0;
+  if (m > 0.0) { (void)frexp(m, &e); e += 1; }          // m = f 2^e, f in [0.5, 1)  ->  m <= 2^e  ->  |y| 2^-(e+1) <= 1/2
+  yscale[d] = ldexp(1.0, e);
+}
+__global__ void __launch_bounds__(256) i8_slice_y_kernel(const double* __restrict__ Kaug, long ld, long Np, int Mp, int Dp, int LDK,
+                                                         const double* __restrict__ yscale, int8_t* __restrict__ Sl, long strideJ) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= Dp) return;
+  const double inv = 1.0 / yscale[d];
+  for (long nb = blockIdx.y; nb < Np / 16; nb += gridDim.y) {
+    unsigned pk[I8S][4];
+#pragma unroll
+    for (int j = 0; j < I8S; ++j) { pk[j][0] = pk[j][1] = pk[j][2] = pk[j][3] = 0u; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double t = Kaug[(nb * 16 + i) * ld + Mp + d] * inv;
+#pragma unroll
+      for (int j = 0; j < I8S; ++j) {
+        t *= 128.0;
+        const double dg = __builtin_rint(t);
+        t -= dg;
+        pk[j][i >> 2] |= ((unsigned)(int)dg & 0xffu) << (8 * (i & 3));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < I8S; ++j) {
+      uint4 v = {pk[j][0], pk[j][1], pk[j][2], pk[j][3]};
+      *(uint4*)(Sl + (long)j * strideJ + ((nb * (long)LDK) + Mp + d) * 16) = v;
+    }
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------------------
+struct I8Plan {
+  int8_t* Sl = nullptr; long strideJ = 0;
+  double* yscale = nullptr; double* pmax = nullptr;
+  I8Job* jobs = nullptr; I8Out* outs = nullptr;
+  int blocks = 0, nouts = 0;
+  bool y_valid = false;
+};
+
+// Psi1's digits come from psi1_kernel's four-waves-across-the-columns form (Mp >= 512, Q <= 16) with fixed embeddings
+bool p1i8_applicable(const gp_ctx* c) {
+  // from 65536 rows on: below that a workgroup's slice is a few hundred k-steps and the float64 kernels are as fast; and with few rows per
+  // inducing point the truncation of the operands weighs more (N = 5e3, M = 600: 2.7e-5 on grad_Z with five digits)
+  return g_opt_p1_i8.load() != 0 && !c->i8_unsupported && c->regime_A && c->N >= 65536 && c->Mp >= 512 && psi1_qp(c->Q) > 0 && psi1_qp(c->Q) <= 16 && p2_fast_mode(c);
+}
+
+int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ) {
+  I8Plan* pl = static_cast<I8Plan*>(c->i8plan);
+  if (c->i8_unsupported) return GP_ERR_UNSUPPORTED;
+  if (!pl) {
+    // published only when complete: a failure below frees what was allocated and switches the path off for this context
+    struct Guard { gp_ctx* c; I8Plan* p; ~Guard() { if (p) { c->i8plan = p; p1i8_free(c); c->i8_unsupported = true; } } };
+    pl = new I8Plan();
+    Guard guard{c, pl};
+    const int MT = c->Mp / TILE, DT = c->Dp / TILE;
+    pl->strideJ = (c->Np / 16) * (long)c->LDK * 16;
+    GP_HIP(c, hipMalloc((void**)&pl->Sl, (size_t)I8S * pl->strideJ));
+    GP_HIP(c, hipMalloc((void**)&pl->yscale, (size_t)c->Dp * sizeof(double)));
+    GP_HIP(c, hipMalloc((void**)&pl->pmax, (size_t)1024 * c->Dp * sizeof(double)));
+    // tiles of one n-slice: Psi2 upper tiles, then the C tiles; slices per XCD chosen for whole rounds of the XCD's 32 CUs (one workgroup
+    // per CU: 320 accumulator registers), every tile of a slice on ONE XCD so that the slice's digits are fetched from HBM once
+    std::vector<int> tiles;                                 // (row block, column block) of 128 combined columns [Psi1 | Y]
+    for (int i = 0; i < MT; ++i) for (int j = i; j < MT; ++j) { tiles.push_back(i); tiles.push_back(j); }
+    for (int i = 0; i < MT; ++i) for (int j = 0; j < DT; ++j) { tiles.push_back(i); tiles.push_back(MT + j); }
+    const int T = (int)tiles.size() / 2;
+    constexpr int SLOTS = 32;                               // resident workgroups per XCD: one per CU (120 KB of LDS)
+    const long ksteps = c->Np / 32;
+    const int s8min = (int)std::max<long>(1, (c->Np + 8 * I8_MAX_ROWS - 1) / (8 * I8_MAX_ROWS));
+    int s8 = s8min; double best = 1e30;
+    for (int t = s8min; t <= s8min + 8; ++t) {
+      const double cost = std::ceil((double)t * T / (double)SLOTS) / t;
+      if (cost < best - 1e-9) { best = cost; s8 = t; }
+    }
+    const int Smax = (int)(c->part_doubles / ((size_t)T * TILE * TILE));          // the partial buffer holds S x T tiles
+    int S = (int)std::min<long>(std::min<long>(8L * s8, ksteps), Smax);
+    if (S < 1 || (c->Np + S - 1) / S + 32 > 87000) return fail(c, GP_ERR_UNSUPPORTED, "int8 phase 1: partial buffer too small for %d tiles", T);
+    // placement: block b runs on XCD b % 8, one workgroup per CU, 32 CUs per XCD.  Whole slices first (every tile of a slice on one XCD: the
+    // slice's digits are fetched from HBM once); when a single round fits (T <= 32) the CUs left over on each XCD are pooled into "shared"
+    // slices whose tiles are spread over the XCDs (their digits are fetched by several XCDs: 2 of 18 slices at M = 512, D = 100)
+    std::vector<std::vector<I8Job>> per_xcd(8);
+    int n_shared = 0;
+    if (T <= SLOTS && S == 8 * (SLOTS / T) && s8 == SLOTS / T) {
+      const int left = SLOTS - (SLOTS / T) * T;
+      n_shared = (int)std::min<long>((8 * left) / T, std::min<long>(Smax - S, ksteps - S));
+      if (n_shared < 0) n_shared = 0;
+    }
+    const int Stot = S + n_shared;
+    for (int s = 0; s < S; ++s) {
+      const int k0 = (int)((long)s * ksteps / Stot), k1 = (int)((long)(s + 1) * ksteps / Stot);
+      for (int t = 0; t < T; ++t) per_xcd[s % 8].push_back(I8Job{tiles[2 * t], tiles[2 * t + 1], k0, k1, s * T + t, 0, 0, 0});
+    }
+    {
+      int x = 0;
+      for (int s = S; s < Stot; ++s) {
+        const int k0 = (int)((long)s * ksteps / Stot), k1 = (int)((long)(s + 1) * ksteps / Stot);
+        for (int t = 0; t < T; ++t) {
+          while ((int)per_xcd[x].size() >= SLOTS) x = (x + 1) & 7;
+          per_xcd[x].push_back(I8Job{tiles[2 * t], tiles[2 * t + 1], k0, k1, s * T + t, 0, 0, 0});
+        }
+      }
+    }
+    S = Stot;
+    size_t depth = 0;
+    for (auto& v : per_xcd) depth = std::max(depth, v.size());
+    std::vector<I8Job> jobs(depth * 8, I8Job{-1, 0, 0, 0, 0, 0, 0, 0});
+    for (int x = 0; x < 8; ++x) for (size_t j = 0; j < per_xcd[x].size(); ++j) jobs[j * 8 + x] = per_xcd[x][j];   // block b runs on XCD b % 8
+    std::vector<I8Out> outs;
+    for (int t = 0; t < T; ++t) outs.push_back(I8Out{tiles[2 * t], tiles[2 * t + 1], t, S, T, tiles[2 * t + 1] >= MT ? 1 : 0, 0, 0});
+    GP_HIP(c, hipMalloc((void**)&pl->jobs, jobs.size() * sizeof(I8Job)));
+    GP_HIP(c, hipMalloc((void**)&pl->outs, outs.size() * sizeof(I8Out)));
+    GP_HIP(c, hipMemcpyAsync(pl->jobs, jobs.data(), jobs.size() * sizeof(I8Job), hipMemcpyHostToDevice, c->stream));
+    GP_HIP(c, hipMemcpyAsync(pl->outs, outs.data(), outs.size() * sizeof(I8Out), hipMemcpyHostToDevice, c->stream));
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+    pl->blocks = (int)jobs.size(); pl->nouts = (int)outs.size();
+    pl->y_valid = false;
+    guard.p = nullptr;
+    c->i8plan = pl;
+  }
+  if (!c->i8_y_valid) pl->y_valid = false;
+  if (!pl->y_valid) {
+    const int nb = 1024;
+    hipLaunchKernelGGL(i8_colmax_kernel, dim3(nb), dim3(256), 0, c->stream, c->Kaug, (long)c->LDK, (long)c->Np, c->Mp, c->Dp, pl->pmax);
+    hipLaunchKernelGGL(i8_yscale_kernel, dim3((c->Dp + 255) / 256), dim3(256), 0, c->stream, pl->pmax, nb, c->Dp, pl->yscale);
+    hipLaunchKernelGGL(i8_slice_y_kernel, dim3((c->Dp + 255) / 256, (unsigned)std::min<long>(c->Np / 16, 4096)), dim3(256), 0, c->stream, c->Kaug, (long)c->LDK,
+                       (long)c->Np, c->Mp, c->Dp, c->LDK, pl->yscale, pl->Sl, pl->strideJ);
+    GP_HIP(c, hipGetLastError());
+    pl->y_valid = true;
+    c->i8_y_valid = true;
+  }
+  *Sl = pl->Sl; *strideJ = pl->strideJ;
+  return GP_OK;
+}
+
+int run_phase1_i8(gp_ctx* c) {
+  I8Plan* pl = static_cast<I8Plan*>(c->i8plan);
+  if (!pl || !pl->y_valid) return fail(c, GP_ERR_STATE, "int8 phase 1 without its digit buffers (psi1 did not write them)");
+  I8Args a;
+  a.Sl = pl->Sl; a.strideJ = pl->strideJ; a.LDK = c->LDK; a.jobs = pl->jobs; a.part = c->part;
+  constexpr int lds = I8_STAGES * I8_STAGE;
+  GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(p1i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  (void)hipEventRecord(c->ev[10], c->stream);
+  hipLaunchKernelGGL(p1i8_kernel, dim3(pl->blocks), dim3(512), lds, c->stream, a);
+  (void)hipEventRecord(c->ev[11], c->stream);
+  GP_HIP(c, hipGetLastError());
+  double* Psi2 = c->stats;
+  double* C = c->stats + (long)c->Mp * c->Mp;
+  // K = 2 sf2 t  (t = the sliced value, |t| <= 1/2)
+  hipLaunchKernelGGL(p1i8_reduce_kernel, dim3(TILE * TILE / 256, pl->nouts), dim3(256), 0, c->stream, c->part, pl->outs, pl->yscale, 4.0 * c->sf2 * c->sf2,
+                     2.0 * c->sf2, Psi2, C, c->Mp, c->Dp);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
+}
+
+void p1i8_free(gp_ctx* c) {
+  I8Plan* pl = static_cast<I8Plan*>(c->i8plan);
+  if (!pl) return;
+  for (void* p : {(void*)pl->Sl, (void*)pl->yscale, (void*)pl->pmax, (void*)pl->jobs, (void*)pl->outs}) if (p) (void)hipFree(p);
+  delete pl;
+  c->i8plan = nullptr;
+}
+
+}  // namespace gp

@@ -109,10 +109,12 @@ constexpr int PSI1_ROWS = 128;   // row granule of psi1_kernel (Np is a multiple
 // sqrt(alpha) o mu (scaled while they are staged), z is scaled once per lane and the exponent is -1/2 sum_q (mu' - z')^2:
 // 2 Q + 18 issue slots per element instead of 3 Q + 20, and nothing per point depends on the hyper-parameters (the prep
 // kernels are skipped from the second evaluation on).
-template <int QP, bool FIXA>
+// SL > 0 (int8 phase 1, p1i8.hip; only the WC = 4 form, where a wave walks all 16 rows of a group): the element is also written as SL signed
+// 7-bit digits of t = Psi1 / (2 sf2) in (0, 1/2], sixteen consecutive rows packed into one 16-byte store per column and digit.
+template <int QP, bool FIXA, int SL = 0>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                    long N, long Np, int M, int Mp, int Q, long ld, int WC, const double* __restrict__ alpha,
-                                                   double lnsf2, int nblk) {
+                                                   double lnsf2, int nblk, int8_t* __restrict__ Sl = nullptr, long strideJ = 0, double hscale = 0.0) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
   // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
   // [mu | u | lnc1] records are staged in LDS (below).
@@ -157,6 +159,56 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       for (int i = 0; i < RPT; ++i) stage[i] = fetch(g + 1, i);
     }
     const double* recs = rec_s[g & 1];
+    if constexpr (SL > 0) {
+      // all 16 rows of the group by this wave (RG = 1), unrolled: the digits of the two columns collect in 2 SL x 4 registers
+      unsigned pk0[SL][4], pk1[SL][4];
+#pragma unroll
+      for (int j = 0; j < SL; ++j) { pk0[j][0] = pk0[j][1] = pk0[j][2] = pk0[j][3] = 0u; pk1[j][0] = pk1[j][1] = pk1[j][2] = pk1[j][3] = 0u; }
+#pragma unroll
+      for (int r = 0; r < GR; ++r) {
+      const long n = row0 + GR * g + r;       // Np is a multiple of 128: always in range
+      const double* row = recs + r * WS;
+      double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const double d0 = row[q] - z0[q], d1 = row[q] - z1[q];
+        if (FIXA) {
+          e0 = fma(d0, d0, e0);
+          e1 = fma(d1, d1, e1);
+        } else {
+          e0 = fma(row[QP + q] * d0, d0, e0);
+          e1 = fma(row[QP + q] * d1, d1, e1);
+        }
+      }
+      const double l0 = FIXA ? lnsf2 : row[2 * QP];
+      const double x0 = fexp_t(fma(-0.5, e0, l0), xt), x1 = fexp_t(fma(-0.5, e1, l0), xt);   // all lanes (cross-lane table lookup), then select
+      double2 v;
+      v.x = (n < N && ok0) ? x0 : 0.0;
+      v.y = (n < N && ok1) ? x1 : 0.0;
+      // non-temporal (one global_store_dwordx4 ... nt per lane): the 4.1 GB of Psi1 is next read after the whole array has been written,
+      // so keeping it in L2 / MALL only evicts what the statistics kernels are about to use -- same-box A/B (three rounds): this kernel
+      // 0.912 -> 0.932 ms, but p1v2_kernel 5.860 -> 5.795 and p2_fast8_kernel 10.051 -> 9.995 ms: evaluation 17.457 -> 17.354 ms
+      if (col < Mp) { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
+        double t0 = v.x * hscale, t1 = v.y * hscale;
+#pragma unroll
+        for (int j = 0; j < SL; ++j) {
+          t0 *= 128.0; t1 *= 128.0;
+          const double g0 = __builtin_rint(t0), g1 = __builtin_rint(t1);
+          t0 -= g0; t1 -= g1;
+          pk0[j][r >> 2] |= ((unsigned)(int)g0 & 0xffu) << (8 * (r & 3));
+          pk1[j][r >> 2] |= ((unsigned)(int)g1 & 0xffu) << (8 * (r & 3));
+        }
+      }
+      if (col < Mp) {
+        int8_t* dst = Sl + (((row0 + GR * g) / 16) * ld + col) * 16;
+#pragma unroll
+        for (int j = 0; j < SL; ++j) {
+          uint4 a0 = {pk0[j][0], pk0[j][1], pk0[j][2], pk0[j][3]}, a1 = {pk1[j][0], pk1[j][1], pk1[j][2], pk1[j][3]};
+          *(uint4*)(dst + (long)j * strideJ) = a0;
+          *(uint4*)(dst + (long)j * strideJ + 16) = a1;
+        }
+      }
+    } else {
 #pragma unroll 1
     for (int r = rg; r < GR; r += RG) {
       const long n = row0 + GR * g + r;       // Np is a multiple of 128: always in range
@@ -182,6 +234,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       // so keeping it in L2 / MALL only evicts what the statistics kernels are about to use -- same-box A/B (three rounds): this kernel
       // 0.912 -> 0.932 ms, but p1v2_kernel 5.860 -> 5.795 and p2_fast8_kernel 10.051 -> 9.995 ms: evaluation 17.457 -> 17.354 ms
       if (col < Mp) { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
+    }
     }
     if (g + 1 < NG) {
 #pragma unroll
@@ -406,6 +459,16 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
   const int WC = c->Mp >= 512 ? 4 : (c->Mp >= 256 ? 2 : 1);
   const int nblk = c->Np >= (1L << 17) ? 4 : 1;                  // 512 rows per workgroup on large shards (still >= 7 workgroups per CU at N = 1e6)
   dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)((c->Np / PSI1_ROWS + nblk - 1) / nblk));
+  if (fixa && WC == 4 && c->i8_active) {
+    // int8 phase 1 (p1i8.hip): Psi1's digits are written next to Psi1 itself
+    int8_t* Sl = nullptr; long strideJ = 0;
+    if (p1i8_prepare(c, &Sl, &strideJ) == GP_OK) {
+      hipLaunchKernelGGL((psi1_kernel<QP, true, GP_I8_DIGITS>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                         (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, Sl, strideJ, 0.5 / c->sf2);
+      return;
+    }
+    c->i8_active = false;
+  }
   if (fixa)
     hipLaunchKernelGGL((psi1_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
                        (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk);
@@ -443,6 +506,7 @@ int run_prep_and_generate(gp_ctx* c) {
     GP_HIP(c, hipGetLastError());
   }
   c->prep_fixa_valid = fixa;
+  c->i8_active = fixa && p1i8_applicable(c);     // decided per evaluation (gp_debug_set_option("p1_i8", ...) switches it at run time)
   (void)hipEventRecord(c->ev[8], c->stream);
   const int QP = psi1_qp(c->Q);
   if (QP > 16) {
@@ -474,6 +538,15 @@ int run_prep_and_generate(gp_ctx* c) {
 }
 
 int run_phase1(gp_ctx* c) {
+  if (c->i8_active) {
+    // fixed embeddings on the int8 matrix core: exact integer products of the 35-bit digits psi1_kernel wrote (p1i8.hip)
+    int rc = run_phase1_i8(c);
+    if (rc != GP_OK) return rc;
+    hipLaunchKernelGGL(p1_scalars_kernel, dim3(1), dim3(256), 0, c->stream, c->klpart, c->kl_blocks, c->sumYY, c->sf2, (double)c->N,
+                       1, c->stats + (long)c->Mp * c->Mp + (long)c->Mp * c->Dp);
+    GP_HIP(c, hipGetLastError());
+    return GP_OK;
+  }
   if (p1v2_applicable(c)) {
     // fixed embeddings / sparse GP: the decomposition without wasted tile slots (p1v2.hip)
     int rc = run_phase1_v2(c);

@@ -200,7 +200,7 @@ int run_phase2(gp_ctx* c);
 bool p2_fast_mode(const gp_ctx* c);
 // p1i8.hip (regime A phase 1 on the int8 matrix core)
 bool p1i8_applicable(const gp_ctx* c);
-int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ);
+int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ, double** Dpart, int row_blocks);
 int run_phase1_i8(gp_ctx* c);
 void p1i8_free(gp_ctx* c);
 // p1v2.hip (regime A phase 1 without wasted tile slots)

@@ -41,8 +41,8 @@ constexpr long I8_MAX_ROWS = 81920;        // rows per workgroup slice (int32 ac
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-std::atomic<int> g_opt_p1_i8{[] { const char* e = getenv("GPARML_P1_I8"); return (e && e[0] == '1') ? 1 : 0; }()};   // off unless asked for
-constexpr int I8L = 8;                     // digit products with a + b <= I8L (digits numbered from 1) are kept
+std::atomic<int> g_opt_p1_i8{[] { const char* e = getenv("GPARML_P1_I8"); return (e && e[0] == '0') ? 0 : 1; }()};   // on where it applies (p1i8_applicable)
+constexpr int I8L = 7;                     // digit products with a + b <= I8L (digits numbered from 1) are kept: 21 of 36
 constexpr int I8O = I8L - 1;               // accumulators: orders a + b = 2 .. I8L
 
 struct I8Job { int ci, cj; int ks0, ks1; int part; int pad0, pad1, pad2; };   // column blocks (128 combined columns), k-steps [ks0, ks1) of 32 rows; ci < 0: idle
@@ -70,24 +70,35 @@ __global__ void __launch_bounds__(512, 1) p1i8_kernel(I8Args a) {
 #pragma unroll
       for (int o = 0; o < I8O; ++o) acc[o][t][i] = 0;
     }
-  // LDS-DMA of one k-step: 4 I8S instructions of 1 KB per panel (a diagonal tile's B panel is its A panel), spread over the eight waves.
-  // Every wave issues the same number per k-step, so `s_waitcnt vmcnt(that number)` means "all but the newest k-step's have landed".
+  // LDS-DMA of one k-step: 4 I8S instructions of 1 KB per panel (a diagonal tile's B panel is its A panel), a fixed set of NDMA slots per wave:
+  // slot e = wave + 8 t covers (panel, digit, row block, column half); its global pointer only advances by one k-step (2 LDK 16 bytes) per
+  // iteration and its LDS offset is constant, so nothing is recomputed in the loop (the first version spent 200 scalar instructions per k-step
+  // and wave on the slot arithmetic).  Every wave issues the same number per k-step: `s_waitcnt vmcnt(NDMA)` = "all but the newest k-step".
   constexpr int NDMA_OFF = 8 * I8S / 8, NDMA_DIAG = (4 * I8S + 7) / 8;
-  auto dma = [&](int ks, int stage) {
+  const int8_t* dsrc[NDMA_OFF];
+  int ddst[NDMA_OFF];
+#pragma unroll
+  for (int t = 0; t < NDMA_OFF; ++t) {
     const int ne = diag ? 4 * I8S : 8 * I8S;
-    for (int e = wave; e < (diag ? 8 * NDMA_DIAG : 8 * NDMA_OFF); e += 8) {
-      const int ee = e < ne ? e : ne - 1;                 // padding slots repeat the last transfer (same data, same place)
-      const int op = ee / (4 * I8S), rem = ee - op * (4 * I8S), j = rem >> 2, h = (rem >> 1) & 1, half = rem & 1;
-      const int col = (op ? job.cj : job.ci) * 128 + 64 * half + lane;
-      const int8_t* src = a.Sl + (long)j * a.strideJ + (((long)(2 * ks + h)) * a.LDK + col) * 16;
-      int8_t* dst = i8lds + stage * I8_STAGE + op * I8_PANEL + ((j * 2 + h) * 128 + 64 * half) * 16;
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
-    }
+    int e = wave + 8 * t;
+    if (e >= ne) e = ne - 1;                              // padding slots repeat the last transfer (same data, same place)
+    const int op = e / (4 * I8S), rem = e - op * (4 * I8S), j = rem >> 2, h = (rem >> 1) & 1, half = rem & 1;
+    dsrc[t] = a.Sl + (long)j * a.strideJ + (((long)(2 * job.ks0 + h)) * a.LDK + (op ? job.cj : job.ci) * 128 + 64 * half + lane) * 16;
+    ddst[t] = op * I8_PANEL + ((j * 2 + h) * 128 + 64 * half) * 16;
+  }
+  const long kstep_bytes = 2L * a.LDK * 16;
+  auto dma = [&](int stage) {
+#pragma unroll
+    for (int t = 0; t < NDMA_OFF; ++t)
+      if (t < NDMA_DIAG || !diag) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)dsrc[t], (lds_void*)(i8lds + stage * I8_STAGE + ddst[t]), 16, 0, 0);
+        dsrc[t] += kstep_bytes;
+      }
   };
   const int kg = lane >> 5, r32 = lane & 31;
   const int nks = job.ks1 - job.ks0;
-  dma(job.ks0, 0);
-  if (nks > 1) dma(job.ks0 + 1, 1);
+  dma(0);
+  if (nks > 1) dma(1);
   for (int i = 0; i < nks; ++i) {
     const int stage = i % I8_STAGES;
     if (i + 1 < nks) { if (diag) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_DIAG) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_OFF) : "memory"); }
@@ -95,23 +106,27 @@ __global__ void __launch_bounds__(512, 1) p1i8_kernel(I8Args a) {
     // stage i has landed for every wave; stage (i + 2) % 3 = (i - 1) % 3 is no longer being read.  A raw barrier: __syncthreads() also waits
     // for vmcnt(0), i.e. for the DMA of k-step i + 1 -- the ring would be one stage deep
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (i + 2 < nks) dma(job.ks0 + i + 2, (i + 2) % I8_STAGES);
+    if (i + 2 < nks) dma((i + 2) % I8_STAGES);
     const int8_t* pa = i8lds + stage * I8_STAGE;
     const int8_t* pb = diag ? pa : pa + I8_PANEL;
-    v4i bv[I8S];
+    v4i bv[I8S], av[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) av[0][ti] = *(const v4i*)(pa + ((0 * 2 + kg) * 128 + wr * 64 + ti * 32 + r32) * 16);
 #pragma unroll
     for (int b = 0; b < I8S; ++b) bv[b] = *(const v4i*)(pb + ((b * 2 + kg) * 128 + wc * 32 + r32) * 16);
+    // digit a of the A panel against digits b <= I8O - 1 - a of the B panel; the next digit's A operands are requested before this digit's MFMAs
 #pragma unroll
     for (int av_ = 0; av_ < I8S; ++av_) {
-      v4i av[2];
+      if (av_ + 1 < I8S) {
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) av[ti] = *(const v4i*)(pa + ((av_ * 2 + kg) * 128 + wr * 64 + ti * 32 + r32) * 16);
+        for (int ti = 0; ti < 2; ++ti) av[(av_ + 1) & 1][ti] = *(const v4i*)(pa + (((av_ + 1) * 2 + kg) * 128 + wr * 64 + ti * 32 + r32) * 16);
+      }
 #pragma unroll
       for (int b = 0; b < I8S; ++b)
         if (b + av_ < I8O) {
 #pragma unroll
           for (int ti = 0; ti < 2; ++ti)
-            acc[av_ + b][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ti], bv[b], acc[av_ + b][ti], 0, 0, 0);
+            acc[av_ + b][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[av_ & 1][ti], bv[b], acc[av_ + b][ti], 0, 0, 0);
         }
     }
   }
@@ -136,7 +151,8 @@ __global__ void __launch_bounds__(512, 1) p1i8_kernel(I8Args a) {
 // sum the slices' partial tiles in a fixed order, apply the operands' scales and write the statistics (both triangles of Psi2)
 struct I8Out { int ci, cj, first, nslices, stride, isC, pad0, pad1; };
 __global__ void __launch_bounds__(256) p1i8_reduce_kernel(const double* __restrict__ part, const I8Out* __restrict__ outs, const double* __restrict__ yscale,
-                                                          double kscale2, double kscale, double* __restrict__ Psi2, double* __restrict__ C, int Mp, int Dp) {
+                                                          double kscale2, double kscale, double* __restrict__ Psi2, double* __restrict__ C, int Mp, int Dp,
+                                                          const double* __restrict__ dpart, int row_blocks) {
   const I8Out o = outs[blockIdx.y];
   const int e = blockIdx.x * 256 + threadIdx.x, r = e >> 7, c = e & 127;
   const double* src = part + (long)o.first * (TILE * TILE) + e;
@@ -154,8 +170,16 @@ __global__ void __launch_bounds__(256) p1i8_reduce_kernel(const double* __restri
     if (d < Dp) C[((long)o.ci * TILE + r) * Dp + d] = s * kscale * yscale[d];
   } else {
     const long R = (long)o.ci * TILE + r, Cc = (long)o.cj * TILE + c;
-    Psi2[R * Mp + Cc] = s * kscale2;
-    if (o.ci != o.cj) Psi2[Cc * Mp + R] = s * kscale2;     // a diagonal tile is computed whole: integer sums, exactly symmetric
+    double v = s * kscale2;
+    if (R == Cc) {
+      // the diagonal of Psi2 from psi1_kernel's float64 sums of squares: the dropped digit products of ONE number with itself do not average out
+      // (neighbouring digits are correlated), and a bias on the diagonal is a jitter on K_mm + beta Psi2
+      double d8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int b = 0; b < row_blocks; ++b) d8[b & 7] += dpart[(long)b * Mp + R];
+      v = ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
+    }
+    Psi2[R * Mp + Cc] = v;
+    if (o.ci != o.cj) Psi2[Cc * Mp + R] = v;               // a diagonal tile is computed whole: integer sums, exactly symmetric
   }
 }
 
@@ -213,6 +237,7 @@ __global__ void __launch_bounds__(256) i8_slice_y_kernel(const double* __restric
 struct I8Plan {
   int8_t* Sl = nullptr; long strideJ = 0;
   double* yscale = nullptr; double* pmax = nullptr;
+  double* dpart = nullptr; int row_blocks = 0;     // [row_blocks][Mp] sums of squares of Psi1's columns per psi1_kernel workgroup (the exact diagonal of Psi2)
   I8Job* jobs = nullptr; I8Out* outs = nullptr;
   int blocks = 0, nouts = 0;
   bool y_valid = false;
@@ -225,7 +250,7 @@ bool p1i8_applicable(const gp_ctx* c) {
   return g_opt_p1_i8.load() != 0 && !c->i8_unsupported && c->regime_A && c->N >= 65536 && c->Mp >= 512 && psi1_qp(c->Q) > 0 && psi1_qp(c->Q) <= 16 && p2_fast_mode(c);
 }
 
-int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ) {
+int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ, double** Dpart, int row_blocks) {
   I8Plan* pl = static_cast<I8Plan*>(c->i8plan);
   if (c->i8_unsupported) return GP_ERR_UNSUPPORTED;
   if (!pl) {
@@ -238,6 +263,8 @@ int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ) {
     GP_HIP(c, hipMalloc((void**)&pl->Sl, (size_t)I8S * pl->strideJ));
     GP_HIP(c, hipMalloc((void**)&pl->yscale, (size_t)c->Dp * sizeof(double)));
     GP_HIP(c, hipMalloc((void**)&pl->pmax, (size_t)1024 * c->Dp * sizeof(double)));
+    pl->row_blocks = row_blocks;
+    GP_HIP(c, hipMalloc((void**)&pl->dpart, (size_t)row_blocks * c->Mp * sizeof(double)));
     // tiles of one n-slice: Psi2 upper tiles, then the C tiles; slices per XCD chosen for whole rounds of the XCD's 32 CUs (one workgroup
     // per CU: 320 accumulator registers), every tile of a slice on ONE XCD so that the slice's digits are fetched from HBM once
     std::vector<int> tiles;                                 // (row block, column block) of 128 combined columns [Psi1 | Y]
@@ -308,7 +335,8 @@ int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ) {
     pl->y_valid = true;
     c->i8_y_valid = true;
   }
-  *Sl = pl->Sl; *strideJ = pl->strideJ;
+  if (pl->row_blocks != row_blocks) return fail(c, GP_ERR_STATE, "int8 phase 1: psi1_kernel's row blocking changed");
+  *Sl = pl->Sl; *strideJ = pl->strideJ; *Dpart = pl->dpart;
   return GP_OK;
 }
 
@@ -327,7 +355,7 @@ int run_phase1_i8(gp_ctx* c) {
   double* C = c->stats + (long)c->Mp * c->Mp;
   // K = 2 sf2 t  (t = the sliced value, |t| <= 1/2)
   hipLaunchKernelGGL(p1i8_reduce_kernel, dim3(TILE * TILE / 256, pl->nouts), dim3(256), 0, c->stream, c->part, pl->outs, pl->yscale, 4.0 * c->sf2 * c->sf2,
-                     2.0 * c->sf2, Psi2, C, c->Mp, c->Dp);
+                     2.0 * c->sf2, Psi2, C, c->Mp, c->Dp, pl->dpart, pl->row_blocks);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }
@@ -335,7 +363,7 @@ int run_phase1_i8(gp_ctx* c) {
 void p1i8_free(gp_ctx* c) {
   I8Plan* pl = static_cast<I8Plan*>(c->i8plan);
   if (!pl) return;
-  for (void* p : {(void*)pl->Sl, (void*)pl->yscale, (void*)pl->pmax, (void*)pl->jobs, (void*)pl->outs}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)pl->Sl, (void*)pl->yscale, (void*)pl->pmax, (void*)pl->dpart, (void*)pl->jobs, (void*)pl->outs}) if (p) (void)hipFree(p);
   delete pl;
   c->i8plan = nullptr;
 }

@@ -114,7 +114,8 @@ constexpr int PSI1_ROWS = 128;   // row granule of psi1_kernel (Np is a multiple
 template <int QP, bool FIXA, int SL = 0>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                    long N, long Np, int M, int Mp, int Q, long ld, int WC, const double* __restrict__ alpha,
-                                                   double lnsf2, int nblk, int8_t* __restrict__ Sl = nullptr, long strideJ = 0, double hscale = 0.0) {
+                                                   double lnsf2, int nblk, int8_t* __restrict__ Sl = nullptr, long strideJ = 0, double hscale = 0.0,
+                                                   double* __restrict__ Dpart = nullptr) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
   // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
   // [mu | u | lnc1] records are staged in LDS (below).
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   const int NG = (int)min((long)nblk * (PSI1_ROWS / GR), (Np - row0) / GR);   // Np is a multiple of 128: whole groups only
   __shared__ double rec_s[2][GR * WS];
   double stage[RPT];
+  double dsq0 = 0.0, dsq1 = 0.0;            // SL > 0: sum of squares of the lane's two columns over this workgroup's rows (the exact diagonal of Psi2, p1i8.hip)
   auto fetch = [&](int g, int i) -> double {
     const int e = threadIdx.x + 256 * i;
     if (e >= GR * WS) return 0.0;
@@ -189,6 +191,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       // so keeping it in L2 / MALL only evicts what the statistics kernels are about to use -- same-box A/B (three rounds): this kernel
       // 0.912 -> 0.932 ms, but p1v2_kernel 5.860 -> 5.795 and p2_fast8_kernel 10.051 -> 9.995 ms: evaluation 17.457 -> 17.354 ms
       if (col < Mp) { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
+        dsq0 = fma(v.x, v.x, dsq0); dsq1 = fma(v.y, v.y, dsq1);
         double t0 = v.x * hscale, t1 = v.y * hscale;
 #pragma unroll
         for (int j = 0; j < SL; ++j) {
@@ -241,6 +244,9 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       for (int i = 0; i < RPT; ++i) { const int e = threadIdx.x + 256 * i; if (e < GR * WS) rec_s[(g + 1) & 1][e] = stage[i]; }
     }
     __syncthreads();
+  }
+  if constexpr (SL > 0) {
+    if (Dpart && col < Mp) { Dpart[(long)blockIdx.y * Mp + col] = dsq0; Dpart[(long)blockIdx.y * Mp + col + 1] = dsq1; }
   }
 }
 
@@ -461,10 +467,10 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
   dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)((c->Np / PSI1_ROWS + nblk - 1) / nblk));
   if (fixa && WC == 4 && c->i8_active) {
     // int8 phase 1 (p1i8.hip): Psi1's digits are written next to Psi1 itself
-    int8_t* Sl = nullptr; long strideJ = 0;
-    if (p1i8_prepare(c, &Sl, &strideJ) == GP_OK) {
+    int8_t* Sl = nullptr; long strideJ = 0; double* Dpart = nullptr;
+    if (p1i8_prepare(c, &Sl, &strideJ, &Dpart, (int)grid.y) == GP_OK) {
       hipLaunchKernelGGL((psi1_kernel<QP, true, GP_I8_DIGITS>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                         (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, Sl, strideJ, 0.5 / c->sf2);
+                         (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, Sl, strideJ, 0.5 / c->sf2, Dpart);
       return;
     }
     c->i8_active = false;

@@ -106,7 +106,11 @@ __global__ void __launch_bounds__(512, 1) p1i8_kernel(I8Args a) {
     // stage i has landed for every wave; stage (i + 2) % 3 = (i - 1) % 3 is no longer being read.  A raw barrier: __syncthreads() also waits
     // for vmcnt(0), i.e. for the DMA of k-step i + 1 -- the ring would be one stage deep
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (i + 2 < nks) dma((i + 2) % I8_STAGES);
+    // An LDS-DMA instruction stalls the wave that issues it for ~65 cycles and nobody else (tools/ubench/dma_wave_ubench.hip: the partner wave on
+    // the same SIMD keeps its full MFMA rate).  The two waves of a SIMD (w and w + 4) therefore stage at different times: the first right behind
+    // the barrier, the second in the middle of its MFMAs -- one of them always feeds the matrix core.
+    const bool early = wave < 4;
+    if (early && i + 2 < nks) dma((i + 2) % I8_STAGES);
     const int8_t* pa = i8lds + stage * I8_STAGE;
     const int8_t* pb = diag ? pa : pa + I8_PANEL;
     v4i bv[I8S], av[2][2];
@@ -117,6 +121,7 @@ __global__ void __launch_bounds__(512, 1) p1i8_kernel(I8Args a) {
     // digit a of the A panel against digits b <= I8O - 1 - a of the B panel; the next digit's A operands are requested before this digit's MFMAs
 #pragma unroll
     for (int av_ = 0; av_ < I8S; ++av_) {
+      if (av_ == 2 && !early && i + 2 < nks) dma((i + 2) % I8_STAGES);
       if (av_ + 1 < I8S) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) av[(av_ + 1) & 1][ti] = *(const v4i*)(pa + (((av_ + 1) * 2 + kg) * 128 + wr * 64 + ti * 32 + r32) * 16);

@@ -1,24 +1,32 @@
-// Phase 1 of the fixed-embedding path on the INT8 matrix core -- the prototype behind VERDICT r03 item 6 (Ozaki-style FP64 on int8), OFF by
-// default (GPARML_P1_I8=1 or gp_debug_set_option("p1_i8", 1) switches it on; DESIGN.md section 6 has the gate's numbers and its outcome):
+// Phase 1 of the fixed-embedding path on the INT8 matrix core (Ozaki-style FP64 on int8; DESIGN.md section 6 has the gate's
+// numbers).  On where it applies (p1i8_applicable: fixed embeddings, N >= 65536, M >= 512, Q <= 16); GPARML_P1_I8=0 or
+// gp_debug_set_option("p1_i8", 0) falls back to the float64 p1v2_kernel.
 //   [Psi2 | C] = K^T [K | Y]   (partial_terms.py:45-52, 79-80; kernel_exp.py:13-49)
 // with the float64 operands split into signed 7-bit digits,
 //   x = scale * sum_{j=1..S} d_j 128^-j,   d_j in [-64, 64],  |x| <= scale / 2,   S = 6 (42 bits below the operand's scale)
-//   x y = scale_x scale_y sum_{a,b} d_a e_b 128^-(a+b),  digit products with a + b <= L = 8 kept (26 of 36),
+//   x y = scale_x scale_y sum_{a,b} d_a e_b 128^-(a+b),  digit products with a + b <= L = 7 kept (21 of 36),
 // each an EXACT integer matrix product on v_mfma_i32_32x32x32_i8 (4.6 POPS measured, 58x the FP64 rate: profiles/r04_i8_ubench.txt);
 // products of equal order a + b share one int32 accumulator.  |d e| <= 4096 and at most S pairs per order, so an accumulator holds
 // 2^31 / (6 * 4096) = 87381 rows: one slice of the shard per workgroup, converted to float64 once at the end.  Integer sums do not depend on
 // the order of accumulation: the digit products are bit-identical for any slicing of the shard.
 //
-// What the gate found (exact CPU emulation of this arithmetic, tests/devtools, and the kernel itself -- they agree to the digit):
+// What the gate found (exact CPU emulation of this arithmetic, tests/devtools/dev_ozaki_gate.py, and the kernel itself -- they agree to the digit):
 //   * which products are dropped matters more than how many digits are kept.  Psi1's entries span ten decades inside a column and their
 //     density falls with magnitude, so inside a digit cell the remainder has a negative mean: neighbouring digits of ONE number are
 //     correlated, and dropping their cross products biases the DIAGONAL of Psi2 (+1e-12 relative with S = 5 / L = 6, 15 products) -- a jitter
 //     on K_mm + beta Psi2 (cond 1e10) that moves grad_Z by 1.2e-5 .. 1.7e-5 from the 80-bit truth at N = 1e6 (measured): outside the contract.
-//     S = 6 / L = 7 (21 products): 3.65e-6 (emulation and kernel, identical).  S = 6 / L = 8 (26 products): bias 2e-16, Psi2 good to
-//     3.5e-15, grad_Z 1.6e-8 -- indistinguishable from float64 statistics.  That is the configuration built here.
-//   * the kernel below reaches ~46 % of the int8 MFMA rate (every LDS-DMA instruction costs its SIMD ~60 cycles of MFMA issue and the panels
-//     are 40 KB per k-step); at that rate 26 products take as long as the float64 p1v2_kernel (5.9 ms at N = 1e6), and psi1_kernel pays
-//     +0.45 ms for writing the digits.  So the float64 matrix core stays in charge; the projected 1.3x is not there.
+//     S = 6 / L = 7 (21 products): 3.65e-6 (emulation and kernel, identical); S = 6 / L = 8 (26 products): 1.6e-8.
+//   * the bias lives on the diagonal, and the diagonal is cheap: psi1_kernel adds up the squares of its two columns per lane while it writes the
+//     digits (float64, one FMA per element), the reduce kernel puts those sums on Psi2's diagonal.  S = 6 / L = 7 with the exact diagonal:
+//     grad_Z 1.1e-7 (N = 1e5) / 4.0e-8 (N = 1e6) from the truth, F 7e-12 -- as good as float64 statistics (1.4e-8 / 3.4e-8), with 21 products
+//     and six accumulator sets (192 registers: two waves per SIMD without spilling; 26 products need seven: one spilled register's reload put a
+//     vmcnt(0) into the loop and serialised the DMA ring).
+//   * speed, same box, N = 1e6: p1v2_kernel 5.8-6.0 ms; this kernel 3.6 ms (64 % of the int8 MFMA rate), psi1_kernel + 0.65 ms for the digits
+//     (1.61 against 0.96: the digit arithmetic, 33 VALU instructions per element, makes it VALU-bound), evaluation - 0.4 .. - 1.4 ms depending on
+//     the box (on some boxes p2_fast8_kernel runs 2-3 % slower behind the int8 kernel).  What lifted the kernel from 46 %: DMA slot arithmetic
+//     precomputed (200 -> 37 scalar instructions per k-step and wave), no spill, a raw s_barrier (__syncthreads() waits for vmcnt(0)), and staging
+//     at different times by the two waves of a SIMD -- an LDS-DMA instruction stalls the wave that issues it for ~65 cycles and nobody else
+//     (tools/ubench/dma_wave_ubench.hip).
 //
 // Digits live in HBM as Sl[j][n / 16][col][16]: the 16 consecutive rows a lane feeds to the matrix core as ONE 16-byte operand, columns =
 // the Mp columns of Psi1 followed by the Dp columns of Y (the layout of Kaug's rows).  Psi1's digits are written by psi1_kernel while it

@@ -124,6 +124,32 @@ def extended_precision_cost(eng, d, N, D, M, Q, seed):
     return res
 
 
+def int8_phase1_variant(eng, d, N, D, M, Q, seed, steps=10):
+    """The same workload with phase 1 on the int8 matrix core (csrc/p1i8.hip, opt-in: exact integer products of six 7-bit digits per operand, 21 digit
+    products, Psi2's diagonal from float64 sums of squares): device ms per evaluation next to the float64 default of the same run, and
+    the distance of ITS gradients from the extended-precision truth.  Timed outside the headline region."""
+    from gparml_amd import _lib
+    lib = _lib.load()
+    res = {}
+    try:
+        for name, on in (('float64 (default, p1v2_kernel)', 0), ('int8 (p1i8_kernel)', 1)):
+            lib.gp_debug_set_option(b'p1_i8', on)
+            eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
+            tot = {}
+            for i in range(steps + 2):
+                out = eng.evaluate(False)
+                if i >= 2:
+                    for k, v in eng.timings().items():
+                        tot[k] = tot.get(k, 0.0) + v / steps
+            te = truth_errors(d, out, N, D, M, Q, seed)
+            res[name] = {'ms_per_eval_device': round(tot['total_ms'], 4), 'psi1_ms': round(tot['psi1_ms'], 4), 'p1_kernel_ms': round(tot['p1_kernel_ms'], 4),
+                         'p2_kernel_ms': round(tot['p2_kernel_ms'], 4), 'grad_Z_err_vs_truth': None if te is None else te['grad_Z_err_vs_truth'],
+                         'F_err_vs_truth': None if te is None else te['F_err_vs_truth']}
+    finally:
+        lib.gp_debug_set_option(b'p1_i8', 0)
+    return res
+
+
 def regime_b_extra(name, N, D, M, Q, device, steps=2, threaded=False):
     """One free-embedding (Bayesian GPLVM, regime B) evaluation shape, timed OUTSIDE the headline region: ms per evaluation (HIP
     events on the engine's stream), SURVEY.md 8(d)'s W_B = N M^2 (4Q + 10) and its fraction of the FP64 peak, the dominant kernels."""
@@ -407,6 +433,8 @@ def main():
             # the price of the two extended-precision pieces: the global step timed (HIP events) with and without them, after the timed region,
             # with grad_Z's distance from the truth for each setting
             res['config']['extended_precision_cost'] = extended_precision_cost(eng, d, N, D, M, Q, 100 + rank)
+            if not a.no_extra and (N, D, M, Q) == (1000000, 100, 512, 10):
+                res['config']['phase1_int8_variant'] = int8_phase1_variant(eng, d, N, D, M, Q, 100 + rank)
         if a.regime == 'A':
             # parity of THIS run's last evaluation against the extended-precision truth of the same workload (rank 0's shard alone:
             # only meaningful for one shard), and the conditioning it was obtained at

@@ -1,6 +1,7 @@
 // Phase 1 of the fixed-embedding path on the INT8 matrix core (Ozaki-style FP64 on int8; DESIGN.md section 6 has the gate's
-// numbers).  On where it applies (p1i8_applicable: fixed embeddings, N >= 65536, M >= 512, Q <= 16); GPARML_P1_I8=0 or
-// gp_debug_set_option("p1_i8", 0) falls back to the float64 p1v2_kernel.
+// numbers).  OPT-IN: GPARML_P1_I8=1 or gp_debug_set_option("p1_i8", 1) switches it on where it applies (p1i8_applicable: fixed embeddings,
+// N >= 65536, M >= 512, Q <= 16); the default stays the float64 p1v2_kernel -- the gain is 2-8 % of an evaluation, and the statistics, while good
+// enough for float64-grade gradients on every workload tried, are 42-bit quantities whose margin on an arbitrary problem is not known.
 //   [Psi2 | C] = K^T [K | Y]   (partial_terms.py:45-52, 79-80; kernel_exp.py:13-49)
 // with the float64 operands split into signed 7-bit digits,
 //   x = scale * sum_{j=1..S} d_j 128^-j,   d_j in [-64, 64],  |x| <= scale / 2,   S = 6 (42 bits below the operand's scale)
@@ -49,7 +50,7 @@ constexpr long I8_MAX_ROWS = 81920;        // rows per workgroup slice (int32 ac
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-std::atomic<int> g_opt_p1_i8{[] { const char* e = getenv("GPARML_P1_I8"); return (e && e[0] == '0') ? 0 : 1; }()};   // on where it applies (p1i8_applicable)
+std::atomic<int> g_opt_p1_i8{[] { const char* e = getenv("GPARML_P1_I8"); return (e && e[0] == '1') ? 1 : 0; }()};   // opt-in (see the header)
 constexpr int I8L = 7;                     // digit products with a + b <= I8L (digits numbered from 1) are kept: 21 of 36
 constexpr int I8O = I8L - 1;               // accumulators: orders a + b = 2 .. I8L
 

@@ -1,6 +1,6 @@
-"""The int8 matrix-core prototype of phase 1 (gparml_amd/csrc/p1i8.hip; OFF by default -- the outcome of the Ozaki gate, DESIGN.md section 6;
+"""Phase 1 on the int8 matrix core (gparml_amd/csrc/p1i8.hip; opt-in -- the outcome of the Ozaki gate, DESIGN.md section 6;
 reference: partial_terms.py:45-52, 79-80 -- Psi2 = sum_n psi2_n, Psi1^T Y -- kernel_exp.py:13-49): exact integer products of six 7-bit
-digits per operand, the 26 digit products with a + b <= 8, instead of float64 MFMAs.
+digits per operand, the 21 digit products with a + b <= 7, Psi2's diagonal from float64 sums of squares, instead of float64 MFMAs.
 
 Checked with the path switched on (gp_debug_set_option('p1_i8', 1)): (1) the statistics against the float64 path of the same library
 (p1v2_kernel) -- they differ by the 2^-42 truncation of the operands and the dropped digit products, 3.5e-15 in the exact CPU emulation;
@@ -37,7 +37,7 @@ def _eval(d, N, D, M, Q, i8):
         assert again['F'] == out['F'] and np.array_equal(again['grad_Z'], out['grad_Z'])          # bit-identical repeat
         eng.close()
     finally:
-        lib.gp_debug_set_option(b'p1_i8', 1)
+        lib.gp_debug_set_option(b'p1_i8', 0)
     return out
 
 
@@ -85,6 +85,7 @@ def test_int8_sums_do_not_depend_on_the_slicing():
     P2, C2 = parts[0].download('PSI2_SUM'), parts[0].download('PSI1TY')
     for e in parts + [one]:
         e.close()
+    lib.gp_debug_set_option(b'p1_i8', 0)
     # Y's digit scale is per shard (its own column maxima), so C may differ by the truncation; Psi2's digits do not depend on the shard
     assert_close(P2, P1, 1e-14, what='Psi2, two shards vs one')       # off the diagonal exact integers; the diagonal is a float64 sum of squares
     assert_close(C2, C1, 1e-9, what='C, two shards vs one')

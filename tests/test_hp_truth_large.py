@@ -1,5 +1,5 @@
 """Parity at the benchmark's own workload and FULL size (BASELINE configs[2]: N=1e6, D=100, M=512, Q=10, alpha=0.1, beta=10,
-bench.py's generator) against an extended-precision truth, on FIVE data / inducing-point draws at N = 1e5 and N = 1e6.
+bench.py's generator) against an extended-precision truth, on TEN data / inducing-point draws at N = 1e5 and N = 1e6.
 
 tests/golden/make_hp_truth_large.py -> oracle/hp_truth.c evaluates the workload in x87 80-bit long double end to end (its own
 uncertainty, measured by re-running the global step on the reversed order of the inducing points: 0.7e-8 .. 2.6e-8 on grad_Z) and stores
@@ -27,8 +27,19 @@ from conftest import GOLDEN_DIR
 BLOCKS = ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta')
 
 
-# (data seed, inducing-point seed): the benchmark's own draw first, then four more data / inducing-point draws (round 4)
-DRAWS = [(100, None), (101, 11), (102, 12), (103, 13), (104, 14)]
+def _draws():
+    """(data seed, inducing-point seed) of every committed truth: the benchmark's own draw first, then the other data / inducing-point draws of round 4
+    (tests/golden/make_hp_truth_large.py N seed z_seed) that exist at BOTH sizes."""
+    import glob
+    import re
+    found = {}
+    for f in glob.glob(os.path.join(GOLDEN_DIR, 'hp_truth_large_N*_s*_z*.npz')):
+        m = re.search(r'_N(\d+)_s(\d+)_z(\d+)\.npz$', f)
+        found.setdefault((int(m.group(2)), int(m.group(3))), set()).add(int(m.group(1)))
+    return [(100, None)] + sorted(k for k, v in found.items() if {100000, 1000000} <= v)
+
+
+DRAWS = _draws()
 
 
 def _fixture(N, seed=100, z_seed=None):
@@ -51,6 +62,7 @@ def _err(x, truth):
 
 
 def test_fixtures_describe_the_benchmark_workload():
+    assert len(DRAWS) >= 5
     for N in (100000, 1000000):
         for seed, z_seed in DRAWS:
             z = _fixture(N, seed, z_seed)

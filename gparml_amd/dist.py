@@ -40,7 +40,19 @@ def init_native_comm(engine, dist, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     box = [engine.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    engine.comm_init(box[0], world, rank)
+    ok = 1
+    try:
+        engine.comm_init(box[0], world, rank)
+    except Exception:                      # RCCL not loadable / communicator refused on this rank
+        ok = 0
+    # every rank must take the same path through the two reductions: agree on the outcome, fall back to torch everywhere otherwise
+    import torch
+    flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if ok:
+            engine.comm_destroy()
+        return False
     return True
 
 

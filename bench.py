@@ -21,7 +21,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-P2_KERNEL = 'gp::p2_fast8_kernel<3>'   # the dominant kernel at the default configuration (Q = 10: three feature groups)
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 (vector = matrix); ubench ceiling 74 (profiles/r01_ubench_f64_mfma4x4x4.txt)
 
 
@@ -380,6 +379,9 @@ def main():
         # algorithmic FLOPs (FMA = 2) of the dominant kernel, the fast phase-2 kernel: K.(2 Bbar) 2NM^2 + Y.Abar^T 2NMD + the
         # n-contraction W^T [mu, 1]: 2NM(Q+1)   (the mu^2 term of grad_alpha only needs row sums)
         flops_p2 = 2.0 * N * M * (M + D) + 2.0 * N * M * (Q + 1)
+        # the kernel run_phase2 (csrc/psi.hip) dispatches for this Q with fixed embeddings: Q + 1 feature columns in groups of four
+        nrb = (Q + 1 + 3) // 4
+        p2_kernel = 'gp::p2_fast8_kernel<%d>' % nrb if nrb <= 3 else ('gp::p2_fast_kernel<%d>' % nrb if Q + 1 <= 24 else 'gp::p2_gen8_kernel<false>')
         ach = flops_p2 / (kern['p2_kernel_ms'] * 1e-3) / 1e12
         # HBM bytes per launch of that kernel from the PMC passes of the SAME command (tools/r02_prof.sh -> profiles/traffic.json,
         # FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes); quoted only while it describes the kernel that ran here
@@ -388,7 +390,7 @@ def main():
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get('kernel') == P2_KERNEL and (tj.get('N'), tj.get('D'), tj.get('M'), tj.get('Q')) == (N, D, M, Q):
+                if tj.get('kernel') == p2_kernel and (tj.get('N'), tj.get('D'), tj.get('M'), tj.get('Q')) == (N, D, M, Q):
                     traffic = tj.get('p2_kernel_hbm_bytes_per_launch')
                     traffic_src = {'file': 'profiles/traffic.json', 'commit': tj.get('commit'), 'date': tj.get('date')}
             except Exception:
@@ -398,15 +400,15 @@ def main():
             'metric': 'variational bound+grad evals/sec', 'value': world * a.steps / dt, 'unit': 'evals/s (one eval = one %d-point shard)' % N,
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[%d]: %d shard(s) x N=%d, D=%d, M=%d, Q=%d, ARD-RBF sparse GP (fixed embeddings)'
-                                   % (2 if world == 1 else 3, world, N, D, M, Q),
+            'config': {'workload': '%s%d shard(s) x N=%d, D=%d, M=%d, Q=%d, ARD-RBF sparse GP (fixed embeddings)'
+                                   % ('BASELINE configs[%d]: ' % (2 if world == 1 else 3) if (N, D, M, Q) == (1000000, 100, 512, 10) else '', world, N, D, M, Q),
                        'N_per_gpu': N, 'D': D, 'M': M, 'Q': Q, 'regime': 'A', 'parallelism': 'dp%d' % world,
                        'points_per_sec': world * N * a.steps / dt, 'F': out['F'],
                        'timed_loop': 'gp_set_globals with new (Z, sf2, alpha, beta) before every evaluation (seeded 1e-3 perturbations; the last step is the '
                                      'unperturbed point); %d distinct bound values in %d steps' % (len(F_seen), a.steps),
                        'device_ms': {k: round(v, 4) for k, v in kern.items()},
                        'eval_flops_survey_8d': W_eval, 'eval_fraction_of_fp64_peak': W_eval / (kern['total_ms'] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-            'roofline': {'bound': 'mfma', 'kernel': P2_KERNEL, 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'roofline': {'bound': 'mfma', 'kernel': p2_kernel, 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src},
         }
         if a.regime == 'B':

@@ -276,10 +276,14 @@ int run_phase1_v2(gp_ctx* c) {
     // slice's jobs on one XCD
     int SF = 0, SG = 0;
     std::vector<int> xF, xG;
-    for (int sg = std::min(std::min(512 / std::max(nG, 1), total_chunks), 1024 / (2 * nG + nF)); sg >= 1; --sg) {
+    // short shards: with fewer than ~24 chunks per workgroup the 512-slot plan spends its time in prologues and in the partial tiles it writes
+    // and the reduce re-reads (N = 1e5, M = 128: 12 chunks each; same-box sweep of the cap, device us per evaluation: 512: 421, 384: 422, 256: 403,
+    // 192: 412, 128: 433) -- one workgroup per CU there
+    const int cap = (long)(nF + nG) * total_chunks < 24L * 512 ? 256 : 512;
+    for (int sg = std::min(std::min(cap / std::max(nG, 1), total_chunks), 2 * cap / (2 * nG + nF)); sg >= 1; --sg) {
       int sf = nF > 0 ? std::max(1, (int)((double)sg * wF / wG + 0.5)) : 0;
       sf = std::min(sf, total_chunks);
-      if ((long)nF * sf + (long)nG * sg > 512) continue;
+      if ((long)nF * sf + (long)nG * sg > cap) continue;
       if (pack_slices(nF, sf, nG, sg, xF, xG)) { SF = sf; SG = sg; break; }
     }
     if (SG == 0) return fail(c, GP_ERR_UNSUPPORTED, "phase-1 planner found no placement (M = %d)", c->M);

@@ -250,8 +250,10 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   }
 }
 
-// Wide latent spaces (17 <= Q <= 64, records padded to QP = 24 / 32 / 52 / 64): the same kernel with ONE column per lane (z_m is QP
-// registers) and four waves = 256 columns per workgroup.  Replaces the generic fallback there (per-element global loads and libm exp:
+// Wide latent spaces (33 <= Q <= 64, records padded to QP = 52 / 64): the same kernel with ONE column per lane (z_m is QP
+// registers) and four waves = 256 columns per workgroup.  17 <= Q <= 32 (QP = 24 / 32) still fit two columns per lane and use psi1_kernel (142 / 170 VGPRs):
+// N = 1e6, M = 512, Q = 30: 2.73 -> 2.47 ms.  Tried here and dropped (r04): the records as scalar loads / SGPR operands instead of LDS broadcasts
+// (every LDS read serves only 64 outputs in this form) -- 4.7 ms at Q = 30: hipcc waits for each s_load_dwordx16 right behind its issue.  Replaces the generic fallback there (per-element global loads and libm exp:
 // 1.8 ms per 2e4 x 1024 at Q = 50 against 0.1 ms of arithmetic).
 template <int QP, bool FIXA>
 __global__ void __launch_bounds__(256) psi1_wide_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
@@ -465,7 +467,7 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
   const int WC = c->Mp >= 512 ? 4 : (c->Mp >= 256 ? 2 : 1);
   const int nblk = c->Np >= (1L << 17) ? 4 : 1;                  // 512 rows per workgroup on large shards (still >= 7 workgroups per CU at N = 1e6)
   dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)((c->Np / PSI1_ROWS + nblk - 1) / nblk));
-  if (fixa && WC == 4 && c->i8_active) {
+  if constexpr (QP <= 16) if (fixa && WC == 4 && c->i8_active) {
     // int8 phase 1 (p1i8.hip): Psi1's digits are written next to Psi1 itself
     int8_t* Sl = nullptr; long strideJ = 0; double* Dpart = nullptr;
     if (p1i8_prepare(c, &Sl, &strideJ, &Dpart, (int)grid.y) == GP_OK) {
@@ -517,8 +519,8 @@ int run_prep_and_generate(gp_ctx* c) {
   const int QP = psi1_qp(c->Q);
   if (QP > 16) {
     switch (QP) {
-      case 24: launch_psi1_wide<24>(c, fixa); break;
-      case 32: launch_psi1_wide<32>(c, fixa); break;
+      case 24: launch_psi1<24>(c, fixa); break;       // two columns per lane as long as 4 QP registers of z fit (psi1_wide_kernel's comment)
+      case 32: launch_psi1<32>(c, fixa); break;
       case 52: launch_psi1_wide<52>(c, fixa); break;
       default: launch_psi1_wide<64>(c, fixa); break;
     }

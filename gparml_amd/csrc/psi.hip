@@ -252,9 +252,11 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
 
 // Wide latent spaces (33 <= Q <= 64, records padded to QP = 52 / 64): the same kernel with ONE column per lane (z_m is QP
 // registers) and four waves = 256 columns per workgroup.  17 <= Q <= 32 (QP = 24 / 32) still fit two columns per lane and use psi1_kernel (142 / 170 VGPRs):
-// N = 1e6, M = 512, Q = 30: 2.73 -> 2.47 ms.  Tried here and dropped (r04): the records as scalar loads / SGPR operands instead of LDS broadcasts
-// (every LDS read serves only 64 outputs in this form) -- 4.7 ms at Q = 30: hipcc waits for each s_load_dwordx16 right behind its issue.  Replaces the generic fallback there (per-element global loads and libm exp:
-// 1.8 ms per 2e4 x 1024 at Q = 50 against 0.1 ms of arithmetic).
+// N = 1e6, M = 512, Q = 30: 2.73 -> 2.47 ms.  Tried here and dropped (r04), all inside 3 % of this form once the fixed-variance arithmetic was used
+// (the kernel is VALU-bound, not LDS-bound): the records as scalar loads / SGPR operands instead of LDS broadcasts (4.7 ms at Q = 30: hipcc waits for each
+// s_load_dwordx16 right behind its issue); a lane PAIR per column pair with the latent dimensions split between the two lanes and one DPP exchange per
+// row (half the LDS reads per output, z in 2 x QP/2 registers: 1.89 vs 1.89 ms at Q = 30, 1.49 vs 1.41 at Q = 20, 1.85 vs 2.03 at Q = 60); the same with
+// explicit ds_read_b64 one chunk ahead (slower: 2.9 ms).
 template <int QP, bool FIXA>
 __global__ void __launch_bounds__(256) psi1_wide_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                         long N, long Np, int M, int Mp, int Q, long ld, const double* __restrict__ alpha,
@@ -517,23 +519,27 @@ int run_prep_and_generate(gp_ctx* c) {
   c->i8_active = fixa && p1i8_applicable(c);     // decided per evaluation (gp_debug_set_option("p1_i8", ...) switches it at run time)
   (void)hipEventRecord(c->ev[8], c->stream);
   const int QP = psi1_qp(c->Q);
+  // The Psi1 kernels' fixed-variance form (u = alpha, ln c1 = ln sf2: 2 Q + 14 issue slots per element instead of 3 Q + 14) only needs every variance
+  // to be zero -- not the fixed-embedding FEATURE layout, which exists for Q + 1 <= 24 -- so it also serves regime A with embedding gradients and
+  // regime A with Q >= 24 (N = 1e6, M = 512, Q = 30: 2.70 -> 1.89 ms).  The int8 digits (launch_psi1) stay tied to `fixa` through c->i8_active.
+  const bool kfix = c->regime_A && a.PU != nullptr;
   if (QP > 16) {
     switch (QP) {
-      case 24: launch_psi1<24>(c, fixa); break;       // two columns per lane as long as 4 QP registers of z fit (psi1_wide_kernel's comment)
-      case 32: launch_psi1<32>(c, fixa); break;
-      case 52: launch_psi1_wide<52>(c, fixa); break;
-      default: launch_psi1_wide<64>(c, fixa); break;
+      case 24: launch_psi1<24>(c, kfix); break;       // two columns per lane as long as 4 QP registers of z fit (psi1_wide_kernel's comment)
+      case 32: launch_psi1<32>(c, kfix); break;
+      case 52: launch_psi1_wide<52>(c, kfix); break;
+      default: launch_psi1_wide<64>(c, kfix); break;
     }
   } else if (QP > 0) {
     switch (QP) {
-      case 2: launch_psi1<2>(c, fixa); break;
-      case 4: launch_psi1<4>(c, fixa); break;
-      case 6: launch_psi1<6>(c, fixa); break;
-      case 8: launch_psi1<8>(c, fixa); break;
-      case 10: launch_psi1<10>(c, fixa); break;
-      case 12: launch_psi1<12>(c, fixa); break;
-      case 14: launch_psi1<14>(c, fixa); break;
-      default: launch_psi1<16>(c, fixa); break;
+      case 2: launch_psi1<2>(c, kfix); break;
+      case 4: launch_psi1<4>(c, kfix); break;
+      case 6: launch_psi1<6>(c, kfix); break;
+      case 8: launch_psi1<8>(c, kfix); break;
+      case 10: launch_psi1<10>(c, kfix); break;
+      case 12: launch_psi1<12>(c, kfix); break;
+      case 14: launch_psi1<14>(c, kfix); break;
+      default: launch_psi1<16>(c, kfix); break;
     }
   } else {
     dim3 grid(c->Mp / 128, (unsigned)(c->Np / 64));

@@ -59,9 +59,11 @@ __global__ void __launch_bounds__(256) prep_elem_kernel(PrepArgs a) {
     const double u = al / (al * s + 1.0);
     a.U[i] = u;
     if (a.PU) { double* rec = a.PU + n * (2 * a.QP + 2); rec[q] = m; rec[a.QP + q] = u; }
-    // per-point features of the n-contraction: fixed embeddings [mu (Q) | 1 | 0 ...], otherwise [u mu (Q) | u (Q) | 1 | 0 ...]
+    // per-point features of the n-contraction: fixed embeddings [mu (Q) | 1 | 0 ...] (fixedA = 1: Q + 1 <= 24, the fast kernels) or
+    // [mu (Q) | 1 | mu^2 (Q) | 0 ...] (fixedA = 2: wider latent spaces on p2_gen8_kernel<false>), otherwise [u mu (Q) | u (Q) | 1 | 0 ...]
     if (a.fixedA) {
       a.Xa[n * a.CXp + q] = (n < a.N) ? m : 0.0;
+      if (a.fixedA == 2) a.Xa[n * a.CXp + a.Q + 1 + q] = (n < a.N) ? m * m : 0.0;
     } else {
       a.Xa[n * a.CXp + q] = (n < a.N) ? u * m : 0.0;
       a.Xa[n * a.CXp + a.Q + q] = (n < a.N) ? u : 0.0;
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(256) prep_row_kernel(PrepArgs a) {
     if (a.PU) a.PU[n * (2 * a.QP + 2) + 2 * a.QP] = lnc;
     const int c1 = a.fixedA ? a.Q : 2 * a.Q;   // column of ones
     a.Xa[n * a.CXp + c1] = (n < a.N) ? 1.0 : 0.0;
-    for (int c = c1 + 1; c < a.CXp; ++c) a.Xa[n * a.CXp + c] = 0.0;
+    for (int c = (a.fixedA == 2 ? 2 * a.Q : c1) + 1; c < a.CXp; ++c) a.Xa[n * a.CXp + c] = 0.0;   // fixedA = 2: columns Q + 1 .. 2 Q hold mu^2
   }
   red[threadIdx.x] = kl;
   __syncthreads();
@@ -454,6 +456,7 @@ __global__ void p1_scalars_kernel(const double* klpart, int nblocks, double sumY
 
 // ------------------------------------------------------------------------------------------------ host side
 bool p2_fast_mode(const gp_ctx* c);
+bool p2_wide_fixed_mode(const gp_ctx* c);
 
 int run_upload_y(gp_ctx* c, const double* dY) {
   const long total = c->Np * (long)c->Dp;
@@ -504,7 +507,7 @@ int run_prep_and_generate(gp_ctx* c) {
   a.Xmu = c->Xmu; a.Xs = c->Xs; a.dir = c->have_dir ? c->dir : nullptr; a.alpha = c->alpha;
   a.mu = c->mu; a.S = c->S; a.U = c->U; a.lnc1 = c->lnc1; a.Xa = c->Xa; a.klpart = c->klpart;
   a.N = c->N; a.Np = c->Np; a.Q = c->Q; a.CXp = c->CXp; a.step = c->step; a.sf2 = c->sf2;
-  a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = p2_fast_mode(c) ? 1 : 0;
+  a.raw = c->xs_raw ? 1 : 0; a.regimeA = c->regime_A ? 1 : 0; a.fixedA = p2_fast_mode(c) ? 1 : (p2_wide_fixed_mode(c) ? 2 : 0);
   a.QP = psi1_qp(c->Q); a.PU = a.QP > 0 ? c->PU : nullptr;
   // Fixed embeddings with every variance zero (regime A, no embedding gradients): the trial point is X_mu itself, S = 0, the
   // feature matrix is [mu | 1] and KL = 0 -- nothing the prep kernels write depends on the hyper-parameters, so they run once per
@@ -1305,6 +1308,7 @@ __global__ void __launch_bounds__(256) p2_ga_kernel(const double* __restrict__ H
 
 // R = sum of the (slice, wave-row) partials; then the data parts of grad_Z / grad_alpha
 //   fixedA (Xa = [mu, 1]):  gZ = a (R1 - Z R0),  ga = -1/2 sum_m (-2 Z R1 + Z^2 R0) + p2_ga_kernel's mu^2 term   [regime A, fixed embeddings]
+//   fixedA = 2 (Xa = [mu, 1, mu^2]): the same with the mu^2 term from the third block, ga = -1/2 sum_m (R2 - 2 Z R1 + Z^2 R0), R2 = W^T(mu o mu)
 //   general (Xa = [u mu, u, 1]):  gZ = R1 - Z R2'  with R1 = W^T(u mu), R2' = W^T u; ga comes from the per-point kernel
 __global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict__ Rpart, int nparts, int Mp, int CXp, int M, int Q,
                                                         const double* __restrict__ Z, const double* __restrict__ alpha, int fixedA,
@@ -1329,7 +1333,7 @@ __global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict
     if (fixedA) {
       const double r1 = R[q], r0 = R[Q];
       gZ[(long)m * Q + q] = alpha[q] * (r1 - z * r0);
-      gapart[(long)m * Q + q] = -0.5 * (z * z * r0 - 2.0 * z * r1);
+      gapart[(long)m * Q + q] = -0.5 * ((fixedA == 2 ? R[Q + 1 + q] : 0.0) + z * z * r0 - 2.0 * z * r1);
     } else {
       gZ[(long)m * Q + q] = R[q] - z * R[Q + q];
       gapart[(long)m * Q + q] = 0.0;
@@ -1397,10 +1401,14 @@ __global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, int lda
 
 // fixed-embedding fast path: regime A without embedding gradients and Q + 1 <= 24 feature columns
 bool p2_fast_mode(const gp_ctx* c) { return c->regime_A && !c->want_emb && c->Q + 1 <= 24; }
+// fixed embeddings with a wider latent space: the general eight-wave kernel WITHOUT its per-point m-contraction, on the hyper-parameter independent
+// features [mu | 1 | mu^2] (the mu^2 term of grad_alpha comes out of the same n-contraction; no point_kernel, the prep kernels run once per upload).
+// N = 1e6, D = 100, M = 512, Q = 30: phase-2 kernel 13.7 -> 12.0 ms, evaluation 23.6 -> 20.4 ms (same box, with the fixed-variance Psi1 kernel; profiles/r04_shape_sweep.txt)
+bool p2_wide_fixed_mode(const gp_ctx* c) { return c->regime_A && !c->want_emb && c->Q + 1 > 24; }
 
 int run_phase2(gp_ctx* c) {
-  const bool fast = p2_fast_mode(c);
-  const bool ppath = !fast;
+  const bool fast = p2_fast_mode(c), widefix = p2_wide_fixed_mode(c);
+  const bool ppath = !fast && !widefix;
   P2Args p;
   p.Kaug = c->Kaug; p.ld = c->LDK; p.Bm = c->Bm; p.Xa = c->Xa; p.Zaug = c->Zaug; p.Rpart = c->Rpart; p.HZp = c->HZp;
   p.Mp = c->Mp; p.CXp = c->CXp; p.CZp = c->CZp; p.MT = c->Mp / TILE; p.Np = c->Np;
@@ -1423,8 +1431,9 @@ int run_phase2(gp_ctx* c) {
   p.dbg = g8dbg;
 #endif
   if (ppath) hipLaunchKernelGGL((p2_gen8_kernel<true>), dim3(blocks), dim3(512), 0, c->stream, p);
+  if (widefix) hipLaunchKernelGGL((p2_gen8_kernel<false>), dim3(blocks), dim3(512), 0, c->stream, p);
 #ifdef GPARML_GEN8_TIMING
-  if (ppath) {
+  if (ppath || widefix) {
     std::vector<long long> h((size_t)blocks * 64);
     GP_HIP(c, hipMemcpy(h.data(), g8dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
     const char* names[8] = {"first chunk", "k-loop", "Psi1 product", "n-contraction", "m-contraction", "tile barrier", "-", "tile setup"};
@@ -1435,7 +1444,8 @@ int run_phase2(gp_ctx* c) {
     }
   }
 #endif
-  else if (nrb <= 3) {
+  if (!fast) {
+  } else if (nrb <= 3) {
     p.gapart = c->hgpart;
     GP_HIP(c, hipMemsetAsync(c->hgpart, 0, (size_t)blocks * 8 * 4 * nrb * sizeof(double), c->stream));   // blocks past the last slice exit early
     switch (nrb) {
@@ -1460,7 +1470,7 @@ int run_phase2(gp_ctx* c) {
   double* ga = c->grads + (long)c->M * c->Q;
   // T2 is free after the global step: per-row alpha partials [M][Q]
   hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(256), 0, c->stream, c->Rpart, 2 * S, c->Mp, fast ? 4 * nrb : c->CXp, c->M, c->Q, c->Z,
-                     c->alpha, fast ? 1 : 0, gZ, c->T2);
+                     c->alpha, fast ? 1 : (widefix ? 2 : 0), gZ, c->T2);
   GP_HIP(c, hipGetLastError());
   if (ppath) {
     PtArgs a;
@@ -1471,6 +1481,8 @@ int run_phase2(gp_ctx* c) {
     hipLaunchKernelGGL(point_kernel, dim3(c->ga_blocks), dim3(256), (size_t)(a.pb * (c->CZp + c->Q) + c->Q) * sizeof(double), c->stream, a);
     GP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, c->gapart, c->ga_blocks, c->Q, c->Q, ga);
+  } else if (widefix) {
+    hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, (const double*)nullptr, 0, 0, c->Q, ga);
   } else {
     int hb = blocks * 8, hstride = 4 * nrb;          // eight-wave kernel: one partial row per wave
     if (hparts > 0) {                                // four-wave kernel: row sums in HZp, finished by p2_ga_kernel

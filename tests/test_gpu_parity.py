@@ -109,7 +109,10 @@ def test_against_oracle_on_seeded_inputs(N, D, M, Q, regime, alpha):
 FIXED_SHAPES = [s for s in SHAPES if s[4] == 'A'] + [(1500, 6, 200, 11, 'A', 0.2), (700, 5, 140, 12, 'A', 0.2), (600, 4, 70, 23, 'A', 0.1),
                                                      (500, 3, 40, 24, 'A', 0.1), (3000, 40, 300, 6, 'A', 1.0), (2500, 33, 1100, 9, 'A', 2.0),
                                                      (900, 104, 129, 5, 'A', 0.6), (900, 105, 129, 5, 'A', 0.6), (2000, 8, 1500, 10, 'A', 2.0),
-                                                     (1300, 32, 256, 8, 'A', 0.8)]
+                                                     (1300, 32, 256, 8, 'A', 0.8),
+                                                     # Q + 1 > 24: p2_gen8_kernel<false> on the features [mu | 1 | mu^2] (no m-contraction, no point kernel)
+                                                     (700, 7, 150, 30, 'A', 0.05), (900, 104, 129, 50, 'A', 0.03), (400, 3, 300, 63, 'A', 0.03),
+                                                     (1000, 12, 64, 25, 'A', 0.06)]
 
 
 @pytest.mark.parametrize('N,D,M,Q,regime,alpha', FIXED_SHAPES)

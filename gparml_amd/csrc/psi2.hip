@@ -931,11 +931,14 @@ static void launch_pairs_mfma(gp_ctx* c, int S) {
 int run_phase1_b(gp_ctx* c) {
   // gp_last_timings' "p1 kernel" slot: in regime B the Psi2 pair kernel (the C tiles' p1_kernel8 launch recorded the events before)
   (void)hipEventRecord(c->ev[10], c->stream);
-  if (c->b_mfma) {
+  // the matrix-core pair kernel from the 24-wide latent tables on (17 <= Q): same-box, N = 1e5, M = 512, ms of this kernel at Q = 17 / 20 / 24:
+  // 21.4 / 21.4 / 21.8 against 30.5 for psi2_pairs_kernel<24>; at 16 columns the VALU kernel is still ahead (15.3 ms measured against ~17 by the instruction count)
+  if (c->b_mfma || c->QB == 24) {
     // 64 x 64 tiles x n-slices: several rounds of workgroups over the 512 resident slots, >= 256 points per slice
     int S = (int)std::max<long>(1, std::min<long>(32, std::max<long>((2048 + c->n_tiles64 - 1) / c->n_tiles64, c->N / 4096)));
     S = (int)std::min<long>(S, std::max<long>(1, c->N / 256));
     switch (c->QB) {
+      case 24: launch_pairs_mfma<24>(c, S); break;
       case 32: launch_pairs_mfma<32>(c, S); break;
       case 52: launch_pairs_mfma<52>(c, S); break;
       default: launch_pairs_mfma<64>(c, S); break;

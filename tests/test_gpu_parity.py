@@ -75,11 +75,14 @@ SHAPES = [
     (900, 4, 64, 20, 'A', 0.1), (129, 1, 1, 1, 'A', 1.0), (4096, 100, 512, 10, 'A', 0.3),
     (300, 5, 20, 3, 'B', 0.5), (500, 4, 2, 2, 'B', 0.7), (1000, 7, 130, 10, 'B', 0.3), (257, 2, 1, 1, 'B', 1.0),
     (640, 3, 33, 13, 'B', 0.2),
-    # every compiled latent width (4/10/16/24/32/52/64) and more than four 64-column slabs of inducing points
+    # every compiled latent width (4/10/16/24/32/52/64; 6/8 below) and more than four 64-column slabs of inducing points
     (500, 3, 300, 5, 'B', 1.0), (400, 2, 70, 20, 'B', 0.1), (300, 2, 40, 30, 'B', 0.08), (200, 2, 24, 50, 'B', 0.05),
     (150, 2, 12, 60, 'B', 0.05),
     # the tile-pair phase 2 (psi2_sym_kernel): eight slabs (four waves, nine rounds), an odd slab count with a bye, both latent widths
     (600, 3, 512, 10, 'B', 0.3), (260, 2, 200, 4, 'B', 4.0), (800, 2, 700, 7, 'B', 0.3),
+    # the latent widths 6 and 8 (r04) on all three phase-2 forms: tile pairs (three .. sixteen slabs), the column kernel (two slabs), a single slab
+    (500, 3, 300, 6, 'B', 0.8), (450, 2, 256, 8, 'B', 0.5), (300, 4, 100, 5, 'B', 1.0), (300, 4, 100, 8, 'B', 0.6), (200, 2, 30, 6, 'B', 1.0),
+    (1100, 2, 1024, 6, 'B', 0.8),
 ]
 
 

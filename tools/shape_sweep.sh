@@ -28,7 +28,7 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
 print('B %-42s ms %9.3f  frac %.3f  %s' % ('$*', d['ms_per_step'], r['frac'], json.dumps(d['config'].get('kernel_ms', d['config'].get('device_ms')))))"
 }
 if [ "${SWEEP_B:-1}" == "1" ]; then
-runb --N 100000 --D 100 --M 512 --Q 2
+runb --N 100000 --D 100 --M 128 --Q 2
 runb --N 100000 --D 100 --M 512 --Q 5
 runb --N 100000 --D 100 --M 512 --Q 10
 runb --N 100000 --D 100 --M 512 --Q 12

@@ -381,7 +381,7 @@ def main():
         flops_p2 = 2.0 * N * M * (M + D) + 2.0 * N * M * (Q + 1)
         # the kernel run_phase2 (csrc/psi.hip) dispatches for this Q with fixed embeddings: Q + 1 feature columns in groups of four
         nrb = (Q + 1 + 3) // 4
-        p2_kernel = 'gp::p2_fast8_kernel<%d>' % nrb if nrb <= 3 else ('gp::p2_fast_kernel<%d>' % nrb if Q + 1 <= 24 else 'gp::p2_gen8_kernel<false>')
+        p2_kernel = 'gp::p2_fast8_kernel<%d>' % nrb if nrb <= 3 else 'gp::p2_gen8_kernel<false>'
         ach = flops_p2 / (kern['p2_kernel_ms'] * 1e-3) / 1e12
         # HBM bytes per launch of that kernel from the PMC passes of the SAME command (tools/r02_prof.sh -> profiles/traffic.json,
         # FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes); quoted only while it describes the kernel that ran here

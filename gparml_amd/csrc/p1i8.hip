@@ -261,7 +261,7 @@ struct I8Plan {
 bool p1i8_applicable(const gp_ctx* c) {
   // from 65536 rows on: below that a workgroup's slice is a few hundred k-steps and the float64 kernels are as fast; and with few rows per
   // inducing point the truncation of the operands weighs more (N = 5e3, M = 600: 2.7e-5 on grad_Z with five digits)
-  return g_opt_p1_i8.load() != 0 && !c->i8_unsupported && c->regime_A && c->N >= 65536 && c->Mp >= 512 && psi1_qp(c->Q) > 0 && psi1_qp(c->Q) <= 16 && p2_fast_mode(c);
+  return g_opt_p1_i8.load() != 0 && !c->i8_unsupported && c->regime_A && c->N >= 65536 && c->Mp >= 512 && psi1_qp(c->Q) > 0 && psi1_qp(c->Q) <= 16 && !c->want_emb;
 }
 
 int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ, double** Dpart, int row_blocks) {

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) prep_elem_kernel(PrepArgs a) {
     const double u = al / (al * s + 1.0);
     a.U[i] = u;
     if (a.PU) { double* rec = a.PU + n * (2 * a.QP + 2); rec[q] = m; rec[a.QP + q] = u; }
-    // per-point features of the n-contraction: fixed embeddings [mu (Q) | 1 | 0 ...] (fixedA = 1: Q + 1 <= 24, the fast kernels) or
+    // per-point features of the n-contraction: fixed embeddings [mu (Q) | 1 | 0 ...] (fixedA = 1: Q + 1 <= 12, p2_fast8_kernel) or
     // [mu (Q) | 1 | mu^2 (Q) | 0 ...] (fixedA = 2: wider latent spaces on p2_gen8_kernel<false>), otherwise [u mu (Q) | u (Q) | 1 | 0 ...]
     if (a.fixedA) {
       a.Xa[n * a.CXp + q] = (n < a.N) ? m : 0.0;
@@ -523,8 +523,8 @@ int run_prep_and_generate(gp_ctx* c) {
   (void)hipEventRecord(c->ev[8], c->stream);
   const int QP = psi1_qp(c->Q);
   // The Psi1 kernels' fixed-variance form (u = alpha, ln c1 = ln sf2: 2 Q + 14 issue slots per element instead of 3 Q + 14) only needs every variance
-  // to be zero -- not the fixed-embedding FEATURE layout, which exists for Q + 1 <= 24 -- so it also serves regime A with embedding gradients and
-  // regime A with Q >= 24 (N = 1e6, M = 512, Q = 30: 2.70 -> 1.89 ms).  The int8 digits (launch_psi1) stay tied to `fixa` through c->i8_active.
+  // to be zero -- not the fixed-embedding FEATURE layout, which the fast kernel uses for Q + 1 <= 12 -- so it also serves regime A with embedding gradients and
+  // wider latent spaces (when measured: N = 1e6, M = 512, Q = 30: 2.70 -> 1.89 ms).  The int8 digits (launch_psi1) stay tied to `fixa` through c->i8_active.
   const bool kfix = c->regime_A && a.PU != nullptr;
   if (QP > 16) {
     switch (QP) {
@@ -649,10 +649,12 @@ struct P2Args {
 constexpr int SLAB_LD = 66;   // 16 x 64 slab row stride (doubles)
 
 
-// Fast variants for the fixed-embedding regime (no per-point outputs), Q + 1 <= 4 * NRB <= 24.  Per-point features are
+// Fast variant for the fixed-embedding regime (no per-point outputs), Q + 1 <= 4 * NRB <= 12 (r04: the four-wave kernel that served Q + 1 <= 24 is gone --
+// from Q = 12 on p2_gen8_kernel<false> on [mu | 1 | mu^2] is faster: same box, N = 1e6, M = 512, ms of the phase-2 kernel at Q = 12 / 16 / 23: 10.43 / 10.74 / 11.30
+// against 11.27 / 11.35 / 11.51).  Per-point features are
 // Xa = [mu (Q) | 1 | 0..]: R[m][:] = sum_n W[n][m] Xa[n][:] gives W^T mu and W^T 1 (grad_Z, and the z-dependent terms of
 // grad_alpha); the remaining term of grad_alpha, sum_nm W[n][m] mu_nq^2 = sum_n h_n mu_nq^2, only needs the row sums
-// h_n = sum_m W[n][m], which each wave forms from its accumulator registers (p2_ga_kernel finishes it).  Compared with
+// h_n = sum_m W[n][m], which each wave forms from its accumulator registers.  Compared with
 // carrying [mu, mu^2, 1] through the MFMAs this halves the epilogue and the resident R accumulators (no scratch spills).
 // (Running the k-loop in rotated order, own Psi1 columns last, so that the epilogue's re-read of that tile hits L2 was tried
 // and dropped: the four m-tile workgroups of a slice then stream different k-chunks at any moment and stop sharing the slice's
@@ -662,118 +664,7 @@ __device__ __forceinline__ double quad_sum(double v) {   // sum over the four la
   v += __shfl_xor(v, 2);
   return v;
 }
-template <int NRB>
-__global__ void __launch_bounds__(256, 2) p2_fast_kernel(P2Args p) {
-  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
-  if (slice >= p.S) return;
-  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE_LDS_DOUBLES];
-  constexpr int XS = 4 * NRB;                                     // feature columns staged per point
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int wrow0 = wr * WT, wcol0 = wc * WT;
-  double* xa_s = &lds[0][0][0];                                   // [128][XS]   (<= 24.6 KB)
-  double* slab = &lds[0][0][0] + TILE * 24 + wave * (16 * SLAB_LD);  // per wave [16][66]
-  const LaneOfs ofs = lane_offsets<K_CONTIG, FREE_CONTIG>(wrow0, wcol0, lane);
-  const int nc = p.kend - p.kbeg;
-  const int t0 = slice * p.tps, t1 = min(p.ntiles, t0 + p.tps);
-  double r[4][NRB];
-#pragma unroll
-  for (int am = 0; am < 4; ++am)
-#pragma unroll
-    for (int bc = 0; bc < NRB; ++bc) r[am][bc] = 0.0;
-  for (int nt = t0; nt < t1; ++nt) {
-    const long n0 = (long)nt * TILE;
-    const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
-    const double* Bb = p.Bm + (long)p.kbeg * KC * p.Mp + (long)mt * TILE;
-    Acc acc;
-    acc.zero();
-    int kc = 0;
-    tile_dma<K_CONTIG>(lds[0][0], Ab + (long)kc * KC, p.ld, wave, lane);
-    tile_dma<FREE_CONTIG>(lds[0][1], Bb + (long)kc * KC * p.Mp, p.Mp, wave, lane);
-    dma_wait();
-    __syncthreads();
-    for (int c = 0; c < nc; ++c) {
-      const int cur = c & 1;
-      if (c + 1 < nc) {
-        ++kc;
-        int ld_ = lane;
-        asm volatile("" : "+v"(ld_));                             // DMA addressing recomputed per chunk instead of held in registers
-        tile_dma<K_CONTIG>(lds[cur ^ 1][0], Ab + (long)kc * KC, p.ld, wave, ld_);
-        tile_dma<FREE_CONTIG>(lds[cur ^ 1][1], Bb + (long)kc * KC * p.Mp, p.Mp, wave, ld_);
-      }
-      mma_chunk_lo<K_CONTIG, FREE_CONTIG>(lds[cur][0], lds[cur][1], acc, ofs);
-      dma_wait();
-      __syncthreads();
-    }
-    acc.drain();
-    // ---- epilogue: all staging buffers are free now.  Its addressing comes from an OPAQUE copy of the lane id so that
-    // none of it stays live across the k-loop (as loop invariants these values were spilled to scratch).
-    int le = tid;
-    asm volatile("" : "+v"(le));
-    const int e_lane = le & 63;
-    const int lr = e_lane & 15, lk = e_lane >> 4, lj = e_lane & 3;
-    const int srow = 4 * ((e_lane >> 2) & 3) + (e_lane >> 4);
-    const int crow = e_lane & 15, ccg = e_lane >> 4;              // slab load: row, 16-column group (8 consecutive lanes -> 8 rows: the
-                                                                  // 16-byte LDS stores of a lane group hit 32 distinct banks)
-    {
-      const double2* src = reinterpret_cast<const double2*>(p.Xa + n0 * p.CXp);
-      double2* dst = reinterpret_cast<double2*>(xa_s);
-      for (int i = le; i < TILE * (XS / 2); i += 256) { const int row = i / (XS / 2), c2 = i - row * (XS / 2); dst[i] = src[(long)row * (p.CXp / 2) + c2]; }
-    }
-    const double* kbase = p.Kaug + (n0 + wrow0 + crow) * p.ld + (long)mt * TILE + wcol0 + 16 * ccg;
-    double kv[16];     // plain doubles: an array of double2 stays in scratch memory (hipcc does not promote it to registers)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const double2 t = *reinterpret_cast<const double2*>(kbase + 2 * i); kv[2 * i] = t.x; kv[2 * i + 1] = t.y; }
-    __syncthreads();   // xa_s visible to every wave
-    double* hout = p.HZp + (long)(mt * 2 + wc) * p.Np + n0 + wrow0 + srow;   // row sums of W over this wave's 64 columns
-#pragma unroll
-    for (int ar = 0; ar < 4; ++ar) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { double2 t; t.x = kv[2 * i]; t.y = kv[2 * i + 1]; *reinterpret_cast<double2*>(slab + crow * SLAB_LD + 16 * ccg + 2 * i) = t; }
-      if (ar < 3) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const double2 t = *reinterpret_cast<const double2*>(kbase + (long)(16 * (ar + 1)) * p.ld + 2 * i); kv[2 * i] = t.x; kv[2 * i + 1] = t.y; }
-      }
-      double hs = 0.0;
-#pragma unroll
-      for (int bc = 0; bc < 16; ++bc) {
-        const double w = acc.v[ar][bc] * slab[srow * SLAB_LD + 4 * bc + lj];
-        slab[srow * SLAB_LD + 4 * bc + lj] = w;    // each lane overwrites exactly the element it read
-        hs += w;
-      }
-      hs = quad_sum(hs);
-      if (lj == 0) hout[16 * ar] = hs;
-      const double* xrow = xa_s + (wrow0 + 16 * ar) * XS + lj;
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        double a[4], b[NRB];
-#pragma unroll
-        for (int am = 0; am < 4; ++am) a[am] = slab[(4 * k4 + lk) * SLAB_LD + 16 * am + lr];
-#pragma unroll
-        for (int bc = 0; bc < NRB; ++bc) b[bc] = xrow[(4 * k4 + lk) * XS + 4 * bc];
-#pragma unroll
-        for (int am = 0; am < 4; ++am)
-#pragma unroll
-          for (int bc = 0; bc < NRB; ++bc) mfma444_acc(r[am][bc], a[am], b[bc]);
-      }
-    }
-    mfma_drain(r[3][NRB - 1]);
-#pragma unroll
-    for (int am = 0; am < 4; ++am) acc_fence<NRB>(r[am]);
-    __syncthreads();   // slabs / xa_s live in the staging buffers the next tile's DMA overwrites
-  }
-  const int srow = 4 * ((lane >> 2) & 3) + (lane >> 4), lj = lane & 3;
-  double* Rmine = p.Rpart + ((long)(slice * 2 + wr) * p.Mp + (long)mt * TILE + wcol0) * XS;
-#pragma unroll
-  for (int am = 0; am < 4; ++am)
-#pragma unroll
-    for (int bc = 0; bc < NRB; ++bc) {
-      Rmine[(long)(16 * am + srow) * XS + 4 * bc + lj] = (t1 > t0) ? r[am][bc] : 0.0;
-    }
-}
-
-// Eight-wave variant (4 * NRB <= 12, i.e. Q <= 11 -- BASELINE configs[1..3]): the same 128 x 128 workgroup tile with every 64 x 64
+// Eight waves (4 * NRB <= 12, i.e. Q <= 11 -- BASELINE configs[1..3]): a 128 x 128 workgroup tile with every 64 x 64
 // quadrant shared by two waves (64 rows x 32 columns: 32 accumulators), four waves per SIMD, and an epilogue that touches
 // no global memory from registers: the workgroup's Psi1 tile arrives by LDS-DMA in four 16-row slabs per wave (the first
 // one and the tile's Xa rows travel during the last k-chunk, the others while the previous slab is processed), W = G o Psi1
@@ -1287,27 +1178,8 @@ __global__ void __launch_bounds__(512, 4) p2_gen8_kernel(P2Args p) {
 #endif
 }
 
-// grad_alpha's mu^2 term from the row sums: out[block][q] = -1/2 sum_{n in block} (sum_p H[p][n]) mu_nq^2   (fixed tree)
-__global__ void __launch_bounds__(256) p2_ga_kernel(const double* __restrict__ H, int nparts, long N, long Np, int Q,
-                                                    const double* __restrict__ mu, double* __restrict__ gapart) {
-  __shared__ double red[256];
-  __shared__ double hsum[256];
-  const long n = blockIdx.x * 256L + threadIdx.x;
-  double h = 0.0;
-  if (n < N) for (int i = 0; i < nparts; ++i) h += H[(long)i * Np + n];
-  hsum[threadIdx.x] = h;
-  for (int q = 0; q < Q; ++q) {
-    const double m = (n < N) ? mu[n * Q + q] : 0.0;
-    red[threadIdx.x] = -0.5 * h * m * m;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) gapart[(long)blockIdx.x * Q + q] = red[0];
-    __syncthreads();
-  }
-}
-
 // R = sum of the (slice, wave-row) partials; then the data parts of grad_Z / grad_alpha
-//   fixedA (Xa = [mu, 1]):  gZ = a (R1 - Z R0),  ga = -1/2 sum_m (-2 Z R1 + Z^2 R0) + p2_ga_kernel's mu^2 term   [regime A, fixed embeddings]
+//   fixedA (Xa = [mu, 1]):  gZ = a (R1 - Z R0),  ga = -1/2 sum_m (-2 Z R1 + Z^2 R0) + the fast kernel's mu^2 term   [regime A, fixed embeddings]
 //   fixedA = 2 (Xa = [mu, 1, mu^2]): the same with the mu^2 term from the third block, ga = -1/2 sum_m (R2 - 2 Z R1 + Z^2 R0), R2 = W^T(mu o mu)
 //   general (Xa = [u mu, u, 1]):  gZ = R1 - Z R2'  with R1 = W^T(u mu), R2' = W^T u; ga comes from the per-point kernel
 __global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict__ Rpart, int nparts, int Mp, int CXp, int M, int Q,
@@ -1399,12 +1271,12 @@ __global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, int lda
   if (threadIdx.x == 0) out[q] = red[0];
 }
 
-// fixed-embedding fast path: regime A without embedding gradients and Q + 1 <= 24 feature columns
-bool p2_fast_mode(const gp_ctx* c) { return c->regime_A && !c->want_emb && c->Q + 1 <= 24; }
+// fixed-embedding fast path: regime A without embedding gradients and Q + 1 <= 12 feature columns (p2_fast8_kernel)
+bool p2_fast_mode(const gp_ctx* c) { return c->regime_A && !c->want_emb && c->Q + 1 <= 12; }
 // fixed embeddings with a wider latent space: the general eight-wave kernel WITHOUT its per-point m-contraction, on the hyper-parameter independent
 // features [mu | 1 | mu^2] (the mu^2 term of grad_alpha comes out of the same n-contraction; no point_kernel, the prep kernels run once per upload).
 // N = 1e6, D = 100, M = 512, Q = 30: phase-2 kernel 13.7 -> 12.0 ms, evaluation 23.6 -> 20.4 ms (same box, with the fixed-variance Psi1 kernel; profiles/r04_shape_sweep.txt)
-bool p2_wide_fixed_mode(const gp_ctx* c) { return c->regime_A && !c->want_emb && c->Q + 1 > 24; }
+bool p2_wide_fixed_mode(const gp_ctx* c) { return c->regime_A && !c->want_emb && c->Q + 1 > 12; }
 
 int run_phase2(gp_ctx* c) {
   const bool fast = p2_fast_mode(c), widefix = p2_wide_fixed_mode(c);
@@ -1422,7 +1294,6 @@ int run_phase2(gp_ctx* c) {
   p.klast = ((c->D - 1) % KC) / 4 + 1;
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
   const int nrb = (c->Q + 1 + 3) / 4;                // fast path: feature columns [mu (Q) | 1] in groups of four
-  int hparts = 0;                                    // row-sum partial arrays the fast kernels leave in HZp
   (void)hipEventRecord(c->ev[12], c->stream);
   p.dbg = nullptr;
 #ifdef GPARML_GEN8_TIMING
@@ -1444,24 +1315,13 @@ int run_phase2(gp_ctx* c) {
     }
   }
 #endif
-  if (!fast) {
-  } else if (nrb <= 3) {
+  if (fast) {                                        // nrb <= 3
     p.gapart = c->hgpart;
     GP_HIP(c, hipMemsetAsync(c->hgpart, 0, (size_t)blocks * 8 * 4 * nrb * sizeof(double), c->stream));   // blocks past the last slice exit early
     switch (nrb) {
       case 1: hipLaunchKernelGGL((p2_fast8_kernel<1>), dim3(blocks), dim3(512), 0, c->stream, p); break;
       case 2: hipLaunchKernelGGL((p2_fast8_kernel<2>), dim3(blocks), dim3(512), 0, c->stream, p); break;
       default: hipLaunchKernelGGL((p2_fast8_kernel<3>), dim3(blocks), dim3(512), 0, c->stream, p); break;
-    }
-  } else {
-    hparts = 2 * p.MT;
-    switch (nrb) {
-      case 1: hipLaunchKernelGGL((p2_fast_kernel<1>), dim3(blocks), dim3(256), 0, c->stream, p); break;
-      case 2: hipLaunchKernelGGL((p2_fast_kernel<2>), dim3(blocks), dim3(256), 0, c->stream, p); break;
-      case 3: hipLaunchKernelGGL((p2_fast_kernel<3>), dim3(blocks), dim3(256), 0, c->stream, p); break;
-      case 4: hipLaunchKernelGGL((p2_fast_kernel<4>), dim3(blocks), dim3(256), 0, c->stream, p); break;
-      case 5: hipLaunchKernelGGL((p2_fast_kernel<5>), dim3(blocks), dim3(256), 0, c->stream, p); break;
-      default: hipLaunchKernelGGL((p2_fast_kernel<6>), dim3(blocks), dim3(256), 0, c->stream, p); break;
     }
   }
   (void)hipEventRecord(c->ev[13], c->stream);
@@ -1484,12 +1344,7 @@ int run_phase2(gp_ctx* c) {
   } else if (widefix) {
     hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, (const double*)nullptr, 0, 0, c->Q, ga);
   } else {
-    int hb = blocks * 8, hstride = 4 * nrb;          // eight-wave kernel: one partial row per wave
-    if (hparts > 0) {                                // four-wave kernel: row sums in HZp, finished by p2_ga_kernel
-      hb = (int)((c->N + 255) / 256); hstride = c->Q;
-      hipLaunchKernelGGL(p2_ga_kernel, dim3(hb), dim3(256), 0, c->stream, c->HZp, hparts, (long)c->N, (long)c->Np, c->Q, c->mu, c->hgpart);
-      GP_HIP(c, hipGetLastError());
-    }
+    const int hb = blocks * 8, hstride = 4 * nrb;    // one partial row of grad_alpha's mu^2 term per wave
     hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, c->hgpart, hb, hstride, c->Q, ga);
   }
   GP_HIP(c, hipGetLastError());

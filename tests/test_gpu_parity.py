@@ -106,14 +106,14 @@ def test_against_oracle_on_seeded_inputs(N, D, M, Q, regime, alpha):
 
 
 # Fixed embeddings (want_embedding_grads = 0): the kernel sequence bench.py times -- p1_kernel8, global step, the fast phase-2
-# kernels (eight-wave p2_fast8_kernel for Q <= 11, four-wave p2_fast_kernel<NRB> up to Q = 23, general kernel beyond).
+# kernels (p2_fast8_kernel for Q <= 11, p2_gen8_kernel<false> on the features [mu | 1 | mu^2] beyond).
 # Phase 1 (p1v2.hip): MT = ceil(M/128) diagonal+C jobs and MT(MT-1)/2 off-diagonal jobs with their own slice counts; NBY = 8 (D <= 32) or 26
 # (D <= 104) C column groups ride on the diagonal jobs; D > 104 or more than 11 row tiles fall back to the tile-per-workgroup kernel.
 FIXED_SHAPES = [s for s in SHAPES if s[4] == 'A'] + [(1500, 6, 200, 11, 'A', 0.2), (700, 5, 140, 12, 'A', 0.2), (600, 4, 70, 23, 'A', 0.1),
                                                      (500, 3, 40, 24, 'A', 0.1), (3000, 40, 300, 6, 'A', 1.0), (2500, 33, 1100, 9, 'A', 2.0),
                                                      (900, 104, 129, 5, 'A', 0.6), (900, 105, 129, 5, 'A', 0.6), (2000, 8, 1500, 10, 'A', 2.0),
                                                      (1300, 32, 256, 8, 'A', 0.8),
-                                                     # Q + 1 > 24: p2_gen8_kernel<false> on the features [mu | 1 | mu^2] (no m-contraction, no point kernel)
+                                                     # wide latent spaces: p2_gen8_kernel<false> on the features [mu | 1 | mu^2] (no m-contraction, no point kernel)
                                                      (700, 7, 150, 30, 'A', 0.05), (900, 104, 129, 50, 'A', 0.03), (400, 3, 300, 63, 'A', 0.03),
                                                      (1000, 12, 64, 25, 'A', 0.06)]
 

@@ -813,8 +813,8 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   auto A = [&](auto** p, size_t n) { if (rc == GP_OK) rc = balloc(c, p, n); };
   // compiled latent widths; from 25 on the phase-2 kernel is the MFMA one and needs a spare column (QB > Q) for the ones.  r04: 6 and 8 next to 10 -- every
   // pair of every point pays 2 QB + 20 issue slots whatever Q is (N = 1e5, M = 512, same box: Q = 5, 6: 44.6 -> 39.0 ms per evaluation; Q = 7, 8: -4 %, the
-  // tile-pair kernel's row tables are 12 wide at 8 as at 10)
-  c->QB = Q <= 4 ? 4 : Q <= 6 ? 6 : Q <= 8 ? 8 : Q <= 10 ? 10 : Q <= 16 ? 16 : Q <= 24 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : 64;
+  // tile-pair kernel's row tables are 12 wide at 8 as at 10); 12 and 14 next to 16 (the column kernel): Q = 12: 63.9 -> 57.1 ms, Q = 14: 65.8 -> 61.8 ms
+  c->QB = Q <= 4 ? 4 : Q <= 6 ? 6 : Q <= 8 ? 8 : Q <= 10 ? 10 : Q <= 12 ? 12 : Q <= 14 ? 14 : Q <= 16 ? 16 : Q <= 24 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : 64;
   c->b_mfma = Q >= 25 && Q < c->QB;
   A(&c->LE, (size_t)Np * Mp); A(&c->LET, (size_t)Np * Mp); A(&c->Vn, (size_t)Np * Q); A(&c->Wn, (size_t)Np * Q);
   A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB); A(&c->Z1P, (size_t)Mp * c->QB); A(&c->WP, (size_t)Np * c->QB); A(&c->MUP, (size_t)Np * c->QB);
@@ -910,6 +910,8 @@ int run_generate_b(gp_ctx* c) {
     case 6: launch_le<6, 2>(c); break;
     case 8: launch_le<8, 2>(c); break;
     case 10: launch_le<10, 2>(c); break;
+    case 12: launch_le<12, 2>(c); break;
+    case 14: launch_le<14, 2>(c); break;
     case 16: launch_le<16, 2>(c); break;
     case 24: launch_le<24, 2>(c); break;
     case 32: launch_le<32, 1>(c); break;
@@ -962,6 +964,8 @@ int run_phase1_b(gp_ctx* c) {
     case 6: launch_pairs<6>(c, S); break;
     case 8: launch_pairs<8>(c, S); break;
     case 10: launch_pairs<10>(c, S); break;
+    case 12: launch_pairs<12>(c, S); break;
+    case 14: launch_pairs<14>(c, S); break;
     case 16: launch_pairs<16>(c, S); break;
     case 24: launch_pairs<24>(c, S); break;
     case 32: launch_pairs<32>(c, S); break;
@@ -1034,6 +1038,8 @@ int run_phase2_b(gp_ctx* c) {
     case 6: launch_cols<6, true>(c, a); break;
     case 8: launch_cols<8, true>(c, a); break;
     case 10: launch_cols<10, true>(c, a); break;
+    case 12: launch_cols<12, false>(c, a); break;
+    case 14: launch_cols<14, false>(c, a); break;
     case 16: launch_cols<16, false>(c, a); break;
     case 24: launch_cols<24, false>(c, a); break;
     case 32: launch_cols<32, false>(c, a); break;

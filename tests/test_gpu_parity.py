@@ -83,6 +83,8 @@ SHAPES = [
     # the latent widths 6 and 8 (r04) on all three phase-2 forms: tile pairs (three .. sixteen slabs), the column kernel (two slabs), a single slab
     (500, 3, 300, 6, 'B', 0.8), (450, 2, 256, 8, 'B', 0.5), (300, 4, 100, 5, 'B', 1.0), (300, 4, 100, 8, 'B', 0.6), (200, 2, 30, 6, 'B', 1.0),
     (1100, 2, 1024, 6, 'B', 0.8),
+    # widths 12 and 14 (the column kernel), several slab groups and a single slab
+    (500, 3, 300, 11, 'B', 0.4), (400, 2, 200, 12, 'B', 0.4), (350, 4, 130, 13, 'B', 0.3), (300, 2, 50, 14, 'B', 0.3),
 ]
 
 

@@ -1,4 +1,4 @@
-// Regime B (Bayesian GPLVM), phase 2 on TILE PAIRS of the symmetric per-point matrix T_n = Bbar o psi2_n  (Q <= 51).
+// Regime B (Bayesian GPLVM), phase 2 on TILE PAIRS of the symmetric per-point matrix T_n = Bbar o psi2_n  (Q <= 63).
 //   reference: partial_terms.py:190-205, 273-284 (psi2 parts of grad_Z / grad_alpha), 388-394, 421-427 (grad_X_mu / grad_X_S),
 //   kernel_exp.py:126-148 (psi2_n); formulation: SURVEY.md section 7 / oracle/factorised.py phase2.
 //
@@ -163,9 +163,10 @@ __global__ void __launch_bounds__(512, 2) psi2_tile_kernel(PT2Args a) {
         // reads requested behind B(s, j): the rest of step s, the steps s + 1 .. s + RS - 1, and what M(s, 0 .. j - 1) re-requested
         constexpr int last = (s + RS - 1) < 15 ? (s + RS - 1) : 15;
         constexpr int newer = (NQ - 1 - j) + (last - s) * (NQ + 1) + ((s + RS <= 15 && j >= 1) ? j + 1 : 0);
-        static_assert(newer <= 15, "lgkmcnt is a 4-bit counter");
+        // lgkmcnt is a 4-bit counter: with more than fifteen newer requests (QT = 64: sixteen) the wave cannot have issued them all while the
+        // operand of this MFMA was still outstanding, so "at most fifteen outstanding" implies it has landed
 #ifndef GPARML_TILE_ABLATE_READS
-        lgkm_wait<newer>();
+        lgkm_wait<(newer < 15 ? newer : 15)>();
 #else
         if constexpr (s == 0 && j == 0) lgkm_wait<0>();
 #endif
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(256) pt2_gz_reduce_kernel(const double* __rest
   }
 }
 
-int pt2_width(int Q) { return Q <= 3 ? 4 : Q <= 7 ? 8 : Q <= 11 ? 12 : Q <= 15 ? 16 : Q <= 23 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : 0; }
+int pt2_width(int Q) { return Q <= 3 ? 4 : Q <= 7 ? 8 : Q <= 11 ? 12 : Q <= 15 ? 16 : Q <= 23 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : Q <= 63 ? 64 : 0; }
 
 template <int QT>
 static size_t pt2_lds_bytes() { return ((size_t)2 * 64 * (QT + 2) + 2 * 64 * TXS + 2 * 2 * 3 * QT + 2 * 4 * 3 * QT + 8 * 32) * sizeof(double); }
@@ -474,7 +475,8 @@ static int launch_tile(gp_ctx* c, const PT2Args& a) {
   return GP_OK;
 }
 
-// The tile-pair phase 2 applies when a compiled width has room for the column of ones (Q <= 51) and is used from Q = 17 on: the per-point
+// The tile-pair phase 2 applies when a compiled width has room for the column of ones (Q <= 63; r04: the 64-wide instantiation, 230 VGPRs, 156 KB of LDS -- Q = 60, M = 1024, 2e4 points: 89 ms against 161 for
+// psi2_cols_mfma_kernel) and is used from Q = 17 on: the per-point
 // folds and sums do not shrink with Q, so below that the VALU kernels of psi2.hip are faster (same-box, ms of the phase-2 kernel per 1e5
 // points: Q = 4, M = 512: 21.7 (cols) vs 41.8 here; Q = 10, M = 512: 31.7 (psi2_sym) vs 40.5; Q = 16, M = 512: 47.2 vs 56.5;
 // Q = 20, M = 256: 23.1 vs 17.0; Q = 24, M = 512: 93.9 vs 69.7; Q = 50, M = 1024, 2e4 points: 96.4 (psi2_cols_mfma) vs 75.8).
@@ -537,7 +539,8 @@ int run_phase2_b_tiles(gp_ctx* c) {
       case 16: rc = launch_tile<16>(c, a); break;
       case 24: rc = launch_tile<24>(c, a); break;
       case 32: rc = launch_tile<32>(c, a); break;
-      default: rc = launch_tile<52>(c, a); break;
+      case 52: rc = launch_tile<52>(c, a); break;
+      default: rc = launch_tile<64>(c, a); break;
     }
     if (rc != GP_OK) return rc;
     GP_HIP(c, hipGetLastError());

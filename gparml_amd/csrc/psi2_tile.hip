@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) pt2_gz_reduce_kernel(const double* __rest
   }
 }
 
-int pt2_width(int Q) { return Q <= 3 ? 4 : Q <= 7 ? 8 : Q <= 11 ? 12 : Q <= 15 ? 16 : Q <= 23 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : Q <= 63 ? 64 : 0; }
+int pt2_width(int Q) { return Q <= 3 ? 4 : Q <= 7 ? 8 : Q <= 11 ? 12 : Q <= 15 ? 16 : Q <= 23 ? 24 : Q <= 31 ? 32 : Q <= 39 ? 40 : Q <= 51 ? 52 : Q <= 63 ? 64 : 0; }
 
 template <int QT>
 static size_t pt2_lds_bytes() { return ((size_t)2 * 64 * (QT + 2) + 2 * 64 * TXS + 2 * 2 * 3 * QT + 2 * 4 * 3 * QT + 8 * 32) * sizeof(double); }
@@ -539,6 +539,7 @@ int run_phase2_b_tiles(gp_ctx* c) {
       case 16: rc = launch_tile<16>(c, a); break;
       case 24: rc = launch_tile<24>(c, a); break;
       case 32: rc = launch_tile<32>(c, a); break;
+      case 40: rc = launch_tile<40>(c, a); break;
       case 52: rc = launch_tile<52>(c, a); break;
       default: rc = launch_tile<64>(c, a); break;
     }

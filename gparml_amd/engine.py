@@ -169,14 +169,22 @@ class ShardEngine(object):
         reference's 1e-7 jitter when a factorisation failed (partial_terms.py:452-456) and raises LinAlgError if that fails too;
         ``sync=False`` (the evaluators) defers all of that to finish(), the evaluation's single host synchronisation."""
         self._ck(self.lib.gp_global_step_jitter(self.h, int(jitter)), 'gp_global_step')
-        if sync:
+        # An evaluator whose previous evaluation needed the jitter (finish() saw the failed factorisation only after phase 2 had run on its
+        # garbage: the whole phase 2 twice per evaluation, +62 % at N = 1e5, M = 512, Q = 5 with free embeddings) checks the outcome HERE the
+        # next time: still the reference's order -- first without jitter, then with (partial_terms.py:452-456) -- for one extra host wait
+        # instead of a wasted phase 2.  The hint is dropped as soon as a plain factorisation succeeds again.
+        if sync or (jitter == 0 and self._jitter_hint):
+            used = 0
             for _ in range(2):                  # at most one retry per matrix: the mask only grows (Kmm, then Kmm + beta Psi2)
                 try:
                     self.global_status()
+                    self._jitter_hint = used
                     return
                 except _lib.JitterRetry as r:
+                    used = r.mask
                     self._ck(self.lib.gp_global_step_jitter(self.h, r.mask), 'gp_global_step')
             self.global_status()                # a third failure is GP_ERR_NOT_PD -> LinAlgError
+            self._jitter_hint = used
 
     def global_status(self):
         mask = ctypes.c_int(0)
@@ -197,7 +205,11 @@ class ShardEngine(object):
         rc = self.lib.gp_finish(self.h, ctypes.byref(F), gZ.ctypes.data_as(_lib._dp), ctypes.byref(gs),
                                 ga.ctypes.data_as(_lib._dp), ctypes.byref(gb))
         if rc == _lib.GP_RETRY_JITTER:
-            self.global_status()        # raises JitterRetry carrying the mask
+            try:
+                self.global_status()    # raises JitterRetry carrying the mask
+            except _lib.JitterRetry as r:
+                self._jitter_hint = r.mask
+                raise
         self._ck(rc, 'gp_finish')
         return dict(F=F.value, grad_Z=gZ, grad_sf2=gs.value, grad_alpha=ga, grad_beta=gb.value)
 
@@ -220,6 +232,7 @@ class ShardEngine(object):
         return out
 
     regime_A_hint = False
+    _jitter_hint = 0          # the jitter mask the previous evaluation ended up with (global_step)
 
     def set_local_statistics(self, sum_YYT, Psi2, C, sum_exp_K_ii, KL):
         Psi2, p2 = _lib.as_c(np.asarray(Psi2, dtype=np.float64).reshape(self.M, self.M))

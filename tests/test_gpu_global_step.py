@@ -159,17 +159,33 @@ def test_evaluate_recovers_through_the_retry():
     st, _ = _indefinite_stats(d, 5e-8)
 
     class Fixed(ShardEngine):
+        bad = True
+        phase2_calls = 0
+
         def phase1(self):                          # keep the hand-made statistics instead of the shard's own
             ShardEngine.phase1(self)
-            self.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+            if self.bad:
+                self.set_local_statistics(st['sum_YYT'], st['Psi2'], st['C'], st['Psi0'], st['KL'])
+
+        def phase2(self, want=False):
+            self.phase2_calls += 1
+            ShardEngine.phase2(self, want)
 
     eng = Fixed(N, D, M, Q)
     eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
     eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
     a = eng.evaluate(False)
+    assert eng.phase2_calls == 2 and eng._jitter_hint != 0          # the failure was seen in finish(): phase 2 ran twice
     b = DistributedEvaluator(eng).evaluate(False)
+    # the next evaluation checks the factorisation before phase 2 (one wait instead of a wasted phase 2) and gives the same bits
+    assert eng.phase2_calls == 3 and eng._jitter_hint != 0
     assert np.isfinite(a['F']) and a['F'] == b['F']
     assert np.all(np.isfinite(a['grad_Z'])) and np.array_equal(a['grad_Z'], b['grad_Z'])
+    eng.bad = False                                                   # the shard's own (well-conditioned) statistics: the hint is dropped again
+    c1 = eng.evaluate(False)
+    assert eng.phase2_calls == 4 and eng._jitter_hint == 0
+    c2 = eng.evaluate(False)
+    assert eng.phase2_calls == 5 and c1['F'] == c2['F'] and np.array_equal(c1['grad_Z'], c2['grad_Z'])
     eng.close()
 
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     'gp_comm_init': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
     'gp_allreduce': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gp_comm_destroy': (ctypes.c_int, [_vp]),
+    'gp_comm_available': (ctypes.c_int, []),
+    'gp_comm_info': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_i64), ctypes.POINTER(_i64), _dp]),
     'gp_grads_buffer': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     'gp_finish': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     'gp_download': (ctypes.c_int, [_vp, ctypes.c_int, _dp, _i64]),

@@ -473,6 +473,7 @@ extern "C" int gp_scale_buffer(gp_ctx* c, int which, double f) {
   if (which == 1 && c->state < 3) return fail(c, GP_ERR_STATE, "gp_scale_buffer(gradient sums) before gp_phase2");
   GP_HIP(c, hipSetDevice(c->device));
   const long n = which == 0 ? (long)c->Mp * c->Mp + (long)c->Mp * c->Dp + SC_COUNT : (long)c->M * c->Q + c->Q;
+  if (which == 0) c->spack_filled = false;   // the padded buffer is the source of truth: a later unpack needs a new pack
   if (f == 0.0) {
     // a dropped shard: the reference never loads its files (local_MapReduce.py:119-129) -- a memset, so that non-finite values in
     // the dropped shard's sums (0 * inf = nan) cannot reach the reduction
@@ -632,6 +633,7 @@ extern "C" int gp_set_local_statistics(gp_ctx* c, double sum_YYT, const double* 
   sc[SC_SUM_YYT] = sum_YYT; sc[SC_PSI0] = sum_exp_K_ii; sc[SC_KL] = KL; sc[SC_NLOCAL] = sum_exp_K_ii / c->sf2;
   GP_HIP(c, hipMemcpyAsync(c->stats + Mp * Mp + Mp * Dp, sc, sizeof(sc), hipMemcpyHostToDevice, c->stream));
   GP_HIP(c, hipStreamSynchronize(c->stream));
+  c->spack_filled = false;     // the packed payload of an earlier evaluation no longer describes these statistics
   if (c->state < 1) c->state = 1;
   return GP_OK;
 }

@@ -97,6 +97,28 @@ extern "C" int gp_comm_init(gp_ctx* c, const void* unique_id, int nranks, int ra
   return GP_OK;
 }
 
+extern "C" int gp_comm_available(void) { return need_rccl(nullptr); }
+
+extern "C" int gp_comm_info(gp_ctx* c, int* nranks, int* rank, int64_t* stats_bytes, int64_t* grads_bytes, double* probe_sum) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (nranks) *nranks = c->comm ? c->comm_ranks : 0;
+  if (rank) *rank = c->comm ? c->comm_rank : -1;
+  if (stats_bytes) *stats_bytes = 8 * ((int64_t)c->M * (c->M + 1) / 2 + (int64_t)c->M * c->D + SC_COUNT);
+  if (grads_bytes) *grads_bytes = 8 * ((int64_t)c->M * c->Q + c->Q);
+  if (probe_sum) {
+    if (!c->comm) return fail(c, GP_ERR_STATE, "gp_comm_info(probe) before gp_comm_init");
+    GP_HIP(c, hipSetDevice(c->device));
+    // one double per rank through the communicator; the last of the device scalars of the global step is free between evaluations
+    double one = 1.0, *slot = c->gs + GS_COUNT - 1;
+    GP_HIP(c, hipMemcpyAsync(slot, &one, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int rc = g_rccl.AllReduce(slot, slot, 1, kNcclFloat64, kNcclSum, c->comm, c->stream);
+    if (rc != 0) return rccl_fail(c, "ncclAllReduce(probe)", rc);
+    GP_HIP(c, hipMemcpyAsync(probe_sum, slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return GP_OK;
+}
+
 extern "C" int gp_comm_destroy(gp_ctx* c) {
   if (!c) return GP_ERR_BAD_ARG;
   (void)hipSetDevice(c->device);

@@ -25,34 +25,109 @@ def device_tensor(ptr, n, device):
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
+#: why the last init_native_comm on this rank returned False ('' after a success); bench.py prints it on rank 0
+native_comm_reason = ''
+
+
+def _say(rank, why):
+    global native_comm_reason
+    native_comm_reason = why
+    if rank == 0 and why:
+        import sys
+        sys.stderr.write('[gparml_amd.dist] reduce falls back to torch.distributed: %s\n' % why)
+    return False
+
+
+def _bounded(fn, seconds, what, rank):
+    """Run a collective call that may wait for other ranks in a worker thread; if it has not returned after ``seconds`` the process says why
+    and ends with status 75 (os._exit from this very process: nothing is exec'ed, a launcher sees a non-zero child) -- a rank that never
+    arrives at ncclCommInitRank must turn into an error of the job, not into a silent hang."""
+    import os
+    import sys
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box['value'] = fn()
+        except BaseException as e:      # noqa: BLE001  (handed back to the caller's thread)
+            box['error'] = e
+
+    t = threading.Thread(target=run, name='gparml-' + what)
+    t.daemon = True
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        sys.stderr.write('[gparml_amd.dist] rank %d: %s did not return within %.0f s (a peer never arrived?); giving up\n' % (rank, what, seconds))
+        sys.stderr.flush()
+        os._exit(75)
+    if 'error' in box:
+        raise box['error']
+    return box.get('value')
+
+
 def init_native_comm(engine, dist, group=None):
     """Give ``engine`` its own RCCL communicator (gp_comm_init): rank 0 draws the ncclUniqueId, torch.distributed carries the 128 bytes to
     the other ranks, every rank joins.  Returns True when the engine now reduces inside the library (gp_allreduce); False when the
-    engine has no such entry point, the backend is not RCCL (gloo tests) or GPARML_NATIVE_ALLREDUCE=0 -- the caller then keeps using
-    torch.distributed on the device pointers."""
+    engine has no such entry point, the backend is not RCCL (gloo tests), GPARML_NATIVE_ALLREDUCE=0, or ANY rank cannot use RCCL --
+    the caller then keeps using torch.distributed on the device pointers (``native_comm_reason`` says why; rank 0 prints it).
+
+    Nothing collective happens on the new communicator before every rank has agreed -- over torch -- that it can take part: each rank
+    probes RCCL on its own (gp_comm_available, and rank 0 also draws the id: both local), the flags are MIN-all-reduced, and only then
+    is the id broadcast and ncclCommInitRank entered (with a bounded wait, GPARML_COMM_INIT_TIMEOUT seconds, default 180).  A second
+    agreement after the call covers RCCL refusing the communicator on some rank, and a one-double probe all-reduce checks that the
+    communicator really sums over ``world`` ranks."""
     import os
-    if os.environ.get('GPARML_NATIVE_ALLREDUCE', '1') == '0' or not hasattr(engine, 'comm_init'):
-        return False
-    if not dist.is_initialized() or dist.get_backend(group) != 'nccl':
-        return False
+    if os.environ.get('GPARML_NATIVE_ALLREDUCE', '1') == '0':
+        return _say(-1, '')
+    if not hasattr(engine, 'comm_init') or not dist.is_initialized():
+        return _say(-1, '')
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if dist.get_backend(group) != 'nccl':
+        return _say(-1, 'process group backend is %s, not nccl' % dist.get_backend(group))
     if getattr(engine, 'has_comm', False):
         return True
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [engine.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    ok = 1
-    try:
-        engine.comm_init(box[0], world, rank)
-    except Exception:                      # RCCL not loadable / communicator refused on this rank
-        ok = 0
-    # every rank must take the same path through the two reductions: agree on the outcome, fall back to torch everywhere otherwise
     import torch
-    flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 0:
+    dev = torch.device('cuda', int(getattr(engine, 'device', torch.cuda.current_device())))
+    limit = float(os.environ.get('GPARML_COMM_INIT_TIMEOUT', '180'))
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+
+    uid, why = None, ''
+    try:
+        ok = bool(engine.comm_available())
+        if ok and rank == 0:
+            uid = engine.comm_unique_id()
+        if not ok:
+            why = 'RCCL cannot be resolved by the library on rank %d' % rank
+    except Exception as e:      # noqa: BLE001
+        ok, why = False, 'rank %d: %s' % (rank, e)
+    with torch.cuda.device(dev):
+        if not agree(ok):
+            return _say(rank, why or 'a peer rank cannot use RCCL from the library')
+        box = [uid]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group, device=dev)
+        try:
+            _bounded(lambda: engine.comm_init(box[0], world, rank), limit, 'gp_comm_init', rank)
+            ok = True
+        except Exception as e:      # noqa: BLE001  (communicator refused on this rank)
+            ok, why = False, 'rank %d: %s' % (rank, e)
         if ok:
-            engine.comm_destroy()
-        return False
+            try:
+                info = _bounded(lambda: engine.comm_info(probe=True), limit, 'gp_comm_info(probe)', rank)
+                if info['ranks'] != world or info['probe_sum'] != float(world):
+                    ok, why = False, 'rank %d: communicator reports %d ranks, probe sum %r, expected %d' % (rank, info['ranks'], info['probe_sum'], world)
+            except Exception as e:      # noqa: BLE001
+                ok, why = False, 'rank %d: %s' % (rank, e)
+        # every rank must take the same path through the two reductions: agree on the outcome, fall back to torch everywhere otherwise
+        if not agree(ok):
+            if getattr(engine, 'has_comm', False):
+                engine.comm_destroy()
+            return _say(rank, why or 'a peer rank failed in gp_comm_init')
+    _say(rank, '')
     return True
 
 

@@ -116,6 +116,22 @@ class ShardEngine(object):
         _lib.raise_for(lib.gp_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), lib, None, 'gp_comm_unique_id')
         return buf.raw
 
+    @staticmethod
+    def comm_available():
+        """True when RCCL can be resolved in this process (gp_comm_available; nothing collective happens)."""
+        return _lib.load().gp_comm_available() == 0
+
+    def comm_info(self, probe=False):
+        """What this context's communicator saw: {'ranks', 'rank', 'stats_bytes', 'grads_bytes'[, 'probe_sum']}.  ``probe`` all-reduces one
+        1.0 per rank (COLLECTIVE; synchronises the stream): the sum equals the rank count exactly when RCCL connected that many ranks."""
+        nr, rk, sb, gb, ps = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+        self._ck(self.lib.gp_comm_info(self.h, ctypes.byref(nr), ctypes.byref(rk), ctypes.byref(sb), ctypes.byref(gb),
+                                       ctypes.byref(ps) if probe else None), 'gp_comm_info')
+        out = {'ranks': nr.value, 'rank': rk.value, 'stats_bytes': sb.value, 'grads_bytes': gb.value}
+        if probe:
+            out['probe_sum'] = ps.value
+        return out
+
     def comm_init(self, unique_id, nranks, rank):
         assert len(unique_id) == _lib.GP_COMM_ID_BYTES
         buf = ctypes.create_string_buffer(bytes(unique_id), _lib.GP_COMM_ID_BYTES)

@@ -105,6 +105,13 @@ def _streaming_pca(options, names):
     lam, V = numpy.linalg.eigh(scatter)
     order = numpy.argsort(lam)[::-1][:Q]
     lam, V = lam[order], V[:, order]
+    # rank-deficient data (Q beyond the rank of the centred data, or cancellation in the mean correction) leaves zero or slightly negative
+    # trailing eigenvalues: dividing by their root would write inf / nan embeddings without a word (the reference's SVD form divides by a
+    # tiny standard deviation in the same case and returns noise)
+    floor = numpy.finfo(float).eps * max(float(lam[0]), 0.0) * scatter.shape[0]
+    if not (lam[-1] > floor):
+        raise numpy.linalg.LinAlgError('PCA initialisation: the data has fewer than Q = %d principal directions (eigenvalue %d of the scatter '
+                                       'matrix is %.3e against a largest one of %.3e)' % (Q, int(numpy.sum(lam > floor)) + 1, lam[-1], lam[0]))
     V = V * numpy.sign(V[numpy.argmax(numpy.abs(V), axis=0), numpy.arange(V.shape[1])])[None, :]
     mean, std = shift + delta, numpy.sqrt(lam / n_tot)              # X.std(axis=0) of the projected data (ddof = 0)
 

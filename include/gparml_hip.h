@@ -130,6 +130,14 @@ int gp_comm_unique_id(void* id_out_128_bytes);
 int gp_comm_init(gp_ctx* ctx, const void* unique_id_128_bytes, int nranks, int rank);
 int gp_allreduce(gp_ctx* ctx, int which);
 int gp_comm_destroy(gp_ctx* ctx);
+/* Diagnostics for the first multi-GPU run.  gp_comm_available() = GP_OK when RCCL can be resolved in this process (nothing collective
+ * happens: every rank can ask before any rank calls gp_comm_init, and a host agrees on the answer over its own channel -- one rank
+ * without RCCL would otherwise leave the others waiting inside ncclCommInitRank).  gp_comm_info reports what the communicator of this
+ * context saw: nranks / rank as given to ncclCommInitRank (0 / -1 without a communicator), the payload of the two all-reduces in
+ * bytes, and -- when probe_sum is not NULL, COLLECTIVE, synchronises the context's stream -- the all-reduced sum of one double 1.0 per
+ * rank: it equals nranks exactly when RCCL really connected that many ranks. */
+int gp_comm_available(void);
+int gp_comm_info(gp_ctx* ctx, int* nranks, int* rank, int64_t* stats_payload_bytes, int64_t* grads_payload_bytes, double* probe_sum);
 /* calculate_global_statistics + Kmm parts of calculate_global_derivatives (parallel_GPLVM.py:302-369):
  * Kmm, Cholesky of Kmm and Kmm+beta*Psi2, F, dF_d*, grad_beta.  Asynchronous: the launches are enqueued and nothing is
  * read back; the outcome is reported by the first of gp_global_status / gp_finish / gp_download that follows (one host

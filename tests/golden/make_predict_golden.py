@@ -48,7 +48,14 @@ def main():
     orig = pred.likelihood_and_gradient
     # run A: three new points, initial means from the nearest training outputs (predict.py:45-66); run B: one new point started from a random
     # inducing point with one restart (predict.py:38-41, 93-108 -- that branch only works for a single test point: X_mu is one row of Z)
-    for tag, n_test, random_init in (('A', 3, False), ('B', 1, True)):
+    # round 5: what predict.test's INITIALISATION reads (predict.py:45-66: every shard's outputs and trained embeddings) is stored too, and a
+    # run C with a ``mask`` (nearest training output over a subset of the output columns) -- appended AFTER runs A and B so that their random
+    # streams, and therefore their recorded numbers, are what round 4 committed
+    for i in range(len(shards)):
+        name = 'shard_%d' % i
+        rec['train_Y_%d' % i] = np.atleast_2d(np.genfromtxt(os.path.join(dirs['input'], name), delimiter=','))
+        rec['train_X_%d' % i] = np.load(os.path.join(dirs['embeddings'], name + '.embedding.npy'))
+    for tag, n_test, random_init, mask in (('A', 3, False, None), ('B', 1, True, None), ('C', 4, False, [0, 2])):
         Xt = rs.randn(n_test, Q)
         Y_test = np.sin(Xt.dot(W)) + 0.1 * rs.randn(n_test, D)
         rec[tag + '_Y_test'] = Y_test
@@ -66,7 +73,9 @@ def main():
         pred.likelihood_and_gradient = wrapped
         np.random.seed(seed + 1)
         with contextlib.redirect_stdout(io.StringIO()):
-            best = pred.test(trained, Y_test, is_random_init=random_init, random_iterations=3, random_restarts=1)
+            best = pred.test(trained, Y_test, mask=mask, is_random_init=random_init, random_iterations=3, random_restarts=1)
+        if mask is not None:
+            rec[tag + '_mask'] = np.asarray(mask, dtype=np.int64)
         rec[tag + '_n_calls'] = np.int64(len(calls))
         rec[tag + '_best_X_mu'], rec[tag + '_best_X_S'], rec[tag + '_best_likelihood'] = np.asarray(best[0]), np.asarray(best[1]), np.float64(best[2])
         print('predict run %s: %d calls, objective %s -> best likelihood %s' % (tag, len(calls), rec[tag + '_call0_f'], best[2]))

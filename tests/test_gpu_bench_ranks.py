@@ -1,6 +1,9 @@
-"""bench.py's N>1 path on a 1-GPU box: two ranks share device 0 and reduce over gloo (test hooks GPARML_BENCH_*), so the
-barrier / max-over-ranks timing / rank-0 JSON line and the two per-evaluation all-reduces on the library's device buffers
-run exactly as under `torch.distributed.run --nproc-per-node N` with RCCL."""
+"""The N>1 paths on a 1-GPU box: several ranks share device 0 and reduce over gloo (bench.py's test hooks GPARML_BENCH_*), so the
+barrier / max-over-ranks timing / rank-0 JSON line and the two per-evaluation all-reduces on the library's device buffers run exactly
+as under `torch.distributed.run --nproc-per-node N` with RCCL.
+
+Round 5: ONE torchrun launch per world size (every rank imports torch once -- on a cold box that import is the 100 s item): the
+rank script runs its checks under its own process group, destroys it, and then calls bench.main() in the same process."""
 import json
 import os
 import socket
@@ -13,26 +16,35 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
+BENCH_TAIL = r"""
+# bench.py --gpus <world> end to end in the same processes (its own init_process_group / destroy_process_group)
+os.environ['GPARML_BENCH_ONE_DEVICE'] = '1'; os.environ['GPARML_BENCH_BACKEND'] = 'gloo'
+import bench
+sys.argv = ['bench.py', '--gpus', str(world), '--steps', '3', '--warmup', '1'] + %(bench_shape)r
+bench.main()
+print('RANK_OK', rank)
+"""
 
-def test_two_ranks_one_device():
+
+def _launch(tmp_path, name, text, world, timeout):
+    script = tmp_path / name
+    script.write_text(text)
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, GPARML_BENCH_ONE_DEVICE='1', GPARML_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--N', '30000', '--D', '12', '--M', '96', '--Q', '5']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and r.stdout.count('RANK_OK') == world, r.stdout[-2000:] + r.stderr[-6000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res['n_gpus'] == 2 and res['steps'] == 3 and res['scaling'] == 'weak' and res['value'] > 0
-    assert 'roofline' in res and 'cpu_baseline' not in res            # CPU baseline: rank 0 at N=1 only
-    # the same workload on one rank: the global bound of two different shards differs, but the per-rank work is the same
-    r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--N', '30000',
-                         '--D', '12', '--M', '96', '--Q', '5', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r1.returncode == 0, r1.stderr[-2000:]
-    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][0])
-    assert one['n_gpus'] == 1
+    assert res['n_gpus'] == world and res['steps'] == 3 and res['scaling'] == 'weak' and res['value'] > 0
+    assert 'roofline' in res and 'cpu_baseline' not in res and 'extra' not in res            # CPU baseline / extras: rank 0 at N=1 only
+    c = res['config']
+    assert c['allreduce_ms']['total'] > 0 and c['global_ms'] > 0 and len(c['ms_per_step_by_rank']['all']) == world
+    # the self-diagnosis fields of the N > 1 line: over gloo the library has no communicator of its own
+    assert c['collective_backend'] == 'gloo' and c['comm_ranks'] == 0 and c['comm_probe_sum'] is None
+    assert c['allreduce_payload_bytes']['stats'] > c['allreduce_payload_bytes']['grads'] > 0
+    return res
 
 
 RANK_SCRIPT = r"""
@@ -63,21 +75,7 @@ for regime in ('A', 'B'):
             g = eng.download(name)
             assert np.max(np.abs(g - ref[k][a:b])) <= 1e-5 * np.max(np.abs(ref[k])), k
     eng.close()
-dist.destroy_process_group()
-print('RANK_OK', rank)
 """
-
-
-def test_two_rank_evaluation_matches_the_oracle(tmp_path):
-    """Two processes, one shard each (both on device 0, gloo): bound and every gradient equal the oracle's on the
-    concatenated data -- the all-reduce of the packed device buffers is the statistics_reducer (local_MapReduce.py:250-277)."""
-    script = tmp_path / 'rank_script.py'
-    script.write_text(RANK_SCRIPT % {'root': ROOT})
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), str(script)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
-    assert r.returncode == 0 and r.stdout.count('RANK_OK') == 2, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 SCG_RANK_SCRIPT = r"""
@@ -87,9 +85,6 @@ import numpy as np, torch, torch.distributed as dist
 from gparml_amd.resident import ResidentCG, ResidentGD, ResidentModel
 from gparml_amd.scg_adapted import SCG_adapted
 from gparml_amd.gd import GD
-rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-torch.cuda.set_device(0)
-dist.init_process_group('gloo', rank=rank, world_size=world)
 for fname, optimiser, iters in (('pipe_gplvm_2shards.npz', 'scg', 2), ('gdpipe_gplvm_2shards.npz', 'gd', 9)):
     z = np.load(os.path.join(%(root)r, 'tests', 'golden', fname)); g = {k: z[k] for k in z.files}
     M, Q, D, N = int(g['M']), int(g['Q']), int(g['D']), int(g['N'])
@@ -124,20 +119,16 @@ for fname, optimiser, iters in (('pipe_gplvm_2shards.npz', 'scg', 2), ('gdpipe_g
         assert model.n_collectives - n1 == 2            # one evaluation = the two packed buffer all-reduces
     model.close()
 dist.destroy_process_group()
-print('RANK_OK', rank)
 """
 
 
-def test_two_rank_resident_optimisation_reproduces_the_reference_runs(tmp_path):
-    """One shard per process (two processes on device 0, gloo): the reference's 2-shard SCG and GD runs are reproduced call
-    by call -- statistics / gradient all-reduces on the device buffers plus the optimisers' scalar sum / max reductions."""
-    script = tmp_path / 'scg_rank_script.py'
-    script.write_text(SCG_RANK_SCRIPT % {'root': ROOT})
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), str(script)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
-    assert r.returncode == 0 and r.stdout.count('RANK_OK') == 2, r.stdout[-2000:] + r.stderr[-4000:]
+def test_two_ranks_on_one_device(tmp_path):
+    """Two processes, one shard each (both on device 0, gloo), one launch: (1) bound and every gradient equal the oracle's on the
+    concatenated data -- the all-reduce of the packed device buffers is the statistics_reducer (local_MapReduce.py:250-277); (2) the
+    reference's 2-shard SCG and GD runs are reproduced call by call with one shard per process -- statistics / gradient all-reduces on
+    the device buffers plus the optimisers' scalar sum / max reductions (scg_adapted_local_MapReduce.py:59-155); (3) bench.py --gpus 2."""
+    text = (RANK_SCRIPT + SCG_RANK_SCRIPT) % {'root': ROOT} + BENCH_TAIL % {'bench_shape': ['--N', '30000', '--D', '12', '--M', '96', '--Q', '5']}
+    _launch(tmp_path, 'two_rank_script.py', text, 2, 1200)
 
 
 EIGHT_RANK_SCRIPT = r"""
@@ -211,29 +202,13 @@ dist.all_gather_object(alls, (f, vals))
 assert all(abs(o[0] - alls[0][0]) == 0 and np.array_equal(o[1], alls[0][1]) for o in alls)
 model.close()
 dist.destroy_process_group()
-print('RANK_OK', rank)
 """
 
 
 def test_eight_ranks_on_one_device(tmp_path):
-    """world_size 8 (BASELINE configs[3] / [4] run at 8 ranks) on a 1-GPU box: eight processes share device 0 over gloo.  Covers what
-    depends on the rank count: ragged eight-way sharding against the oracle (both regimes), the shared-seed drop-out mask with several
+    """world_size 8 (BASELINE configs[3] / [4] run at 8 ranks) on a 1-GPU box: eight processes share device 0 over gloo, one launch.  Covers
+    what depends on the rank count: ragged eight-way sharding against the oracle (both regimes), the shared-seed drop-out mask with several
     dropped ranks, the jitter retry taken by all ranks together, the resident optimiser reductions, and bench.py --gpus 8 end to end
     with its all-reduce timings."""
-    script = tmp_path / 'eight_rank_script.py'
-    script.write_text(EIGHT_RANK_SCRIPT % {'root': ROOT})
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), str(script)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
-    assert r.returncode == 0 and r.stdout.count('RANK_OK') == 8, r.stdout[-2000:] + r.stderr[-6000:]
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, GPARML_BENCH_ONE_DEVICE='1', GPARML_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1',
-           '--N', '20000', '--D', '12', '--M', '96', '--Q', '5']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-    assert res['n_gpus'] == 8 and res['scaling'] == 'weak' and res['value'] > 0
-    assert res['config']['allreduce_ms']['total'] > 0 and res['config']['global_ms'] > 0 and 'cpu_baseline' not in res and 'extra' not in res
+    text = EIGHT_RANK_SCRIPT % {'root': ROOT} + BENCH_TAIL % {'bench_shape': ['--N', '20000', '--D', '12', '--M', '96', '--Q', '5']}
+    _launch(tmp_path, 'eight_rank_script.py', text, 8, 1500)

@@ -74,3 +74,46 @@ def test_predict_callback_replays_the_reference_runs():
         return p.likelihood_and_gradient
 
     _replay_reference_fixture(make)
+
+
+def run_reference_protocol(make_predictor, xtol, ftol, gtol):
+    """predict.test end to end as the reference ran it (tests/golden/make_predict_golden.py): the same global numpy seed, the training shards and
+    trained embeddings the reference's initialisation read, then -- run A: nearest-training-output start (predict.py:44-66), run B: a random
+    inducing point and one restart keeping the best likelihood (predict.py:38-41, 93-108), run C: nearest output over a column ``mask``.
+    Every evaluation the restated driver makes must be the one the reference made (same flat vector, objective, gradient), the number of
+    evaluations must agree, and so must the returned [X_mu, X_S, likelihood]."""
+    import os
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'predict_gplvm_2shards.npz'))
+    gs = dict(Z=z['global_Z'], sf2=z['global_sf2'], alpha=z['global_alpha'], beta=z['global_beta'])
+    acc = {k: z['acc_' + k] for k in ('sum_YYT', 'sum_exp_K_mi_K_im', 'sum_exp_K_miY', 'sum_exp_K_ii', 'sum_KL')}
+    training = [(z['train_Y_%d' % i], z['train_X_%d' % i]) for i in range(2)]
+    for tag, kw in (('A', dict(training=training)), ('B', dict(is_random_init=True, random_restarts=1)),
+                    ('C', dict(training=training, mask=[int(v) for v in z['C_mask']]))):
+        p = make_predictor(gs, acc, int(z['N']), int(z['D']))
+        calls = []
+        inner = p.likelihood_and_gradient
+
+        def recorded(x, iteration=0, step_size=0, inner=inner, calls=calls):
+            f, g = inner(x, iteration, step_size)
+            calls.append((np.array(x, dtype=float), float(f), np.array(g, dtype=float)))
+            return f, g
+
+        p.likelihood_and_gradient = recorded
+        np.random.seed(32)                                             # make_predict_golden.py: numpy.random.seed(seed + 1) before predict.test
+        best = p.test(z[tag + '_Y_test'], iterations=3, **kw)
+        assert len(calls) == int(z[tag + '_n_calls']), (tag, len(calls))
+        # the starting point is host arithmetic only (k-d tree / random inducing point, clipped variances, softplus inverse): to rounding
+        assert_close(calls[0][0], z[tag + '_call0_x'], 1e-13, what='run %s: x0' % tag)
+        for k, (x, f, g) in enumerate(calls):
+            assert_close(x, z['%s_call%d_x' % (tag, k)], xtol, what='run %s call %d: x' % (tag, k))
+            assert_close(f, z['%s_call%d_f' % (tag, k)], ftol, what='run %s call %d: objective' % (tag, k))
+            assert_close(g, z['%s_call%d_g' % (tag, k)], gtol, what='run %s call %d: gradient' % (tag, k))
+        assert_close(best[0], z[tag + '_best_X_mu'], xtol, what='run %s: best X_mu' % tag)
+        assert_close(best[1], z[tag + '_best_X_S'], xtol, what='run %s: best X_S' % tag)
+        assert_close(best[2], z[tag + '_best_likelihood'], ftol, what='run %s: best likelihood' % tag)
+
+
+def test_predict_test_initialisation_and_restarts_reproduce_the_reference_runs():
+    from gparml_amd.predict import Predictor
+    run_reference_protocol(lambda gs, acc, N, D: Predictor(gs, acc, N, D), 1e-6, 1e-6, 1e-5)

@@ -121,3 +121,13 @@ def test_mp_truth_fixture_documents_the_float64_oracles_limit():
     t = z['truth_grad_Z']
     err = float(np.max(np.abs(ref['grad_Z'] - t)) / np.max(np.abs(t)))
     assert 1e-4 < err < 1e-1 and float(z['cond_A']) > 1e9
+
+
+def test_predict_test_host_logic_reproduces_the_reference_runs_on_the_literal_oracle():
+    """gparml_amd/predict.py's restatement of predict.test (predict.py:19-111: nearest-training-output start with ``mask``, random inducing point,
+    restarts that keep the best likelihood) with the GPU class swapped for the literal CPU restatement: the host logic alone against the
+    reference's recorded runs (the GPU twin is tests/test_gpu_predict.py)."""
+    from gparml_amd.predict import Predictor
+    from oracle import literal as L
+    from test_gpu_predict import run_reference_protocol
+    run_reference_protocol(lambda gs, acc, N, D: Predictor(gs, acc, N, D, partial_terms_class=L.PartialTermsOracle), 1e-8, 1e-9, 1e-8)

@@ -58,8 +58,11 @@ __global__ void scale_kernel(double* x, long n, double f) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] *= f;
 }
 // Zaug[m] = [1, z_m, z_m^2] (rows >= M zero), Z padded copy
-__global__ void zaug_kernel(const double* __restrict__ Zin, int M, int Mp, int Q, int CZp, double* __restrict__ Z, double* __restrict__ Zaug) {
+// Zin / alpha_in are read straight from the pinned host slot of gp_set_globals (mapped memory: M Q + Q doubles over the bus, no copy commands)
+__global__ void zaug_kernel(const double* __restrict__ Zin, const double* __restrict__ alpha_in, int M, int Mp, int Q, int CZp, double* __restrict__ Z,
+                            double* __restrict__ Zaug, double* __restrict__ alpha) {
   const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m < Q) alpha[m] = alpha_in[m];
   if (m >= Mp) return;
   for (int c = 0; c < CZp; ++c) Zaug[(long)m * CZp + c] = 0.0;
   for (int q = 0; q < Q; ++q) {
@@ -181,6 +184,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 4; ++i) if (c->gev[i]) (void)hipEventDestroy(c->gev[i]);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->h_out) (void)hipHostFree(c->h_out);
   for (int i = 0; i < 2; ++i) { if (c->h_glob[i]) (void)hipHostFree(c->h_glob[i]); if (c->glob_ev[i]) (void)hipEventDestroy(c->glob_ev[i]); }
   delete c;
   return GP_OK;
@@ -292,26 +296,27 @@ extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const doub
   for (long i = 0; i < (long)c->M * c->Q; ++i) if (!std::isfinite(Z[i])) return fail(c, GP_ERR_NON_FINITE, "Z is not finite");
   if (N_global < c->N) return fail(c, GP_ERR_BAD_ARG, "N_global (%ld) smaller than the local shard (%ld)", (long)N_global, (long)c->N);
   GP_HIP(c, hipSetDevice(c->device));
-  double* tmp = c->T1;  // scratch for the unpadded Z
   // stage through pinned memory: hipMemcpyAsync from pageable memory blocks the host until the copy has been staged AND used to be followed by a
-  // stream synchronisation here (r03: every evaluation of an optimiser paid it); from a pinned slot the copy is asynchronous and the call returns
-  // after enqueueing -- the evaluation's only host synchronisation is the read-back in gp_finish
+  // stream synchronisation here (r03: every evaluation of an optimiser paid it).  r05: no copy command at all -- zaug_kernel reads the pinned
+  // (mapped) slot itself; two copy commands cost ~25 us of stream time at configs[1]'s size (blit dispatches with idle gaps around them,
+  // profiles/r05_config1_timeline.txt) for 10 KB.  The evaluation's only host synchronisation is the read-back in gp_finish
   const size_t nz = (size_t)c->M * c->Q, nq = (size_t)c->Q;
   const int slot = c->glob_slot;
   if (!c->h_glob[slot]) {
-    GP_HIP(c, hipHostMalloc((void**)&c->h_glob[slot], (nz + nq) * sizeof(double), hipHostMallocDefault));
+    GP_HIP(c, hipHostMalloc((void**)&c->h_glob[slot], (nz + nq) * sizeof(double), hipHostMallocMapped));
     GP_HIP(c, hipEventCreateWithFlags(&c->glob_ev[slot], hipEventDisableTiming));
   } else {
     GP_HIP(c, hipEventSynchronize(c->glob_ev[slot]));   // the copy issued from this slot two calls ago (long complete in any real sequence)
   }
   std::memcpy(c->h_glob[slot], Z, nz * sizeof(double));
   std::memcpy(c->h_glob[slot] + nz, alpha, nq * sizeof(double));
-  GP_HIP(c, hipMemcpyAsync(tmp, c->h_glob[slot], nz * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  GP_HIP(c, hipMemcpyAsync(c->alpha, c->h_glob[slot] + nz, nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  GP_HIP(c, hipEventRecord(c->glob_ev[slot], c->stream));
-  c->glob_slot = slot ^ 1;
-  hipLaunchKernelGGL(zaug_kernel, dim3((c->Mp + 255) / 256), dim3(256), 0, c->stream, tmp, c->M, c->Mp, c->Q, c->CZp, c->Z, c->Zaug);
+  double* dslot = nullptr;
+  GP_HIP(c, hipHostGetDevicePointer((void**)&dslot, c->h_glob[slot], 0));
+  hipLaunchKernelGGL(zaug_kernel, dim3((std::max(c->Mp, c->Q) + 255) / 256), dim3(256), 0, c->stream, dslot, dslot + nz, c->M, c->Mp, c->Q, c->CZp, c->Z,
+                     c->Zaug, c->alpha);
   GP_HIP(c, hipGetLastError());
+  GP_HIP(c, hipEventRecord(c->glob_ev[slot], c->stream));   // the slot may be rewritten once this kernel has read it
+  c->glob_slot = slot ^ 1;
   c->sf2 = sf2; c->beta = beta; c->N_global = N_global; c->step = step;
   c->have_globals = true;
   c->state = 0;
@@ -643,26 +648,42 @@ extern "C" int gp_set_local_statistics(gp_ctx* c, double sum_YYT, const double* 
 __global__ void add_kernel(const double* a, const double* b, double* out, long n) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = a[i] + b[i];
 }
+// gp_finish's only launch: out = [global-step scalars and failure flags (ngs) | Kmm parts + data parts of grad_Z, grad_alpha (n)], written straight
+// into pinned host memory -- one kernel and one stream synchronisation instead of copy, synchronise, kernel, copy, synchronise (r04: the second
+// round trip and the two blit dispatches were ~0.1 ms of wall time per evaluation at configs[1]'s size, profiles/r05_config1_timeline.txt)
+__global__ void finish_kernel(const double* __restrict__ gs, int ngs, const double* __restrict__ a, const double* __restrict__ b, long n,
+                              double* __restrict__ out) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < ngs + n; i += (long)gridDim.x * 256L) out[i] = i < ngs ? gs[i] : a[i - ngs] + b[i - ngs];
+}
 
 extern "C" int gp_finish(gp_ctx* c, double* F, double* grad_Z, double* grad_sf2, double* grad_alpha, double* grad_beta) {
   if (!c) return GP_ERR_BAD_ARG;
   if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_finish before gp_global_step");
   GP_HIP(c, hipSetDevice(c->device));
-  GP_TRY(check_global(c));   // the one host synchronisation of an evaluation: scalars + failure flags of the global step
+  const bool want_grads = grad_Z || grad_alpha;
+  if (want_grads && c->state < 3) {
+    GP_TRY(check_global(c));   // a failed global step is the more useful message
+    return fail(c, GP_ERR_STATE, "gp_finish: gradients requested before gp_phase2");
+  }
+  if (!want_grads) {
+    GP_TRY(check_global(c));
+  } else {
+    // the one host synchronisation of an evaluation: scalars + failure flags of the global step and the final gradients in one mapped buffer
+    const long n = (long)c->M * c->Q + c->Q;
+    constexpr int ngs = GS_COUNT + 8;
+    if (!c->h_out) GP_HIP(c, hipHostMalloc((void**)&c->h_out, (size_t)(ngs + n) * sizeof(double), hipHostMallocMapped));
+    double* dout = nullptr;
+    GP_HIP(c, hipHostGetDevicePointer((void**)&dout, c->h_out, 0));
+    hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(ngs + n)), dim3(256), 0, c->stream, c->gs, ngs, c->gK, c->grads, n, dout);
+    GP_HIP(c, hipGetLastError());
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+    GP_TRY(check_global_from(c, c->gs_pending ? c->h_out : nullptr));
+    if (grad_Z) memcpy(grad_Z, c->h_out + ngs, (size_t)c->M * c->Q * 8);
+    if (grad_alpha) memcpy(grad_alpha, c->h_out + ngs + (size_t)c->M * c->Q, (size_t)c->Q * 8);
+  }
   if (F) *F = c->h_gs[GS_F];
   if (grad_sf2) *grad_sf2 = c->h_gs[GS_GRAD_SF2];
   if (grad_beta) *grad_beta = c->h_gs[GS_GRAD_BETA];
-  if (grad_Z || grad_alpha) {
-    if (c->state < 3) return fail(c, GP_ERR_STATE, "gp_finish: gradients requested before gp_phase2");
-    const long n = (long)c->M * c->Q + c->Q;
-    double* tmp = c->T2;
-    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->gK, c->grads, tmp, n);
-    std::vector<double> h(n);
-    GP_HIP(c, hipMemcpyAsync(h.data(), tmp, n * 8, hipMemcpyDeviceToHost, c->stream));
-    GP_HIP(c, hipStreamSynchronize(c->stream));
-    if (grad_Z) memcpy(grad_Z, h.data(), (size_t)c->M * c->Q * 8);
-    if (grad_alpha) memcpy(grad_alpha, h.data() + (size_t)c->M * c->Q, (size_t)c->Q * 8);
-  }
   return GP_OK;
 }
 // ---- resident CG vectors (scg_adapted_local_MapReduce.py:29-243) --------------------------------------------------------

@@ -2,6 +2,7 @@
 // workgroup, 16-deep k-chunks double-buffered through LDS, two workgroups per CU.
 // Used by the global step (M x M algebra) and, through the same building blocks, by the phase kernels.
 #include "gp_common.h"
+#include "gemm32.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -74,107 +75,13 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
   }
 }
 
-// Small-tile variant for the latency-bound products of the global step (M x M x {M, D, 128} with M a few hundred).  One CU
-// delivers 0.29 TFLOP/s of FP64 MFMA, so a 128 x 128 x 128 tile product takes 15 us on the CU that owns it whatever the
-// kernel does; those products have 1 to 16 such tiles and left 94 % of the chip idle (eight-wave 128-tile kernel: 21 us per
-// launch).  Here a workgroup owns a 32 x 32 output tile (four waves, 16 x 16 each: one A and four B operand registers, four
-// accumulators) and walks K in chunks of 128 staged through LDS from registers (one global round trip per chunk, the next
-// chunk's loads in flight during the MFMAs), so a 128^3 product is sixteen workgroups of 0.9 us MFMA time each.
-//   LDS image of an operand chunk: K_CONTIG  [32 free][128 k], row stride 130  (16 rows x {k, k+1} cover 32 distinct 8-byte slots)
-//                                  FREE_CONTIG [128 k][32 free], row stride 48 (k and k+1 sit 16 slots apart)
-// Operand reads are explicit ds_read_b64 with counted lgkmcnt waits (mma_f64.h).
-
-constexpr int ST = 32;     // workgroup tile of the small kernel
-constexpr int SKC = 128;   // its k-chunk
-template <Layout L> struct SmallImg {
-  static constexpr int LD = (L == K_CONTIG) ? SKC + 2 : ST + 16;
-  static constexpr int DOUBLES = (L == K_CONTIG) ? ST * LD : SKC * LD;
-};
-
-// this thread's 8 x 16 bytes of a [32 x 128] operand chunk; kleft = K - k0 (a multiple of 16; elements beyond it read as zero)
-template <Layout L>
-__device__ __forceinline__ void small_load(const double* __restrict__ src, long ld, int kleft, int tid, double2 (&r)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = tid + 256 * i;
-    const int k = (L == K_CONTIG) ? 2 * (e & 63) : (e >> 4);
-    const double* g = (L == K_CONTIG) ? src + (long)(e >> 6) * ld + k : src + (long)k * ld + 2 * (e & 15);
-    r[i] = (k < kleft) ? *reinterpret_cast<const double2*>(g) : make_double2(0.0, 0.0);
-  }
-}
-template <Layout L>
-__device__ __forceinline__ void small_store(double* img, int tid, const double2 (&r)[8]) {
-  constexpr int LD = SmallImg<L>::LD;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = tid + 256 * i;
-    double* d = (L == K_CONTIG) ? img + (e >> 6) * LD + 2 * (e & 63) : img + (e >> 4) * LD + 2 * (e & 15);
-    *reinterpret_cast<double2*>(d) = r[i];
-  }
-}
-
+// Small-tile variant for the latency-bound products of the global step: see gemm32.h (the tile product is a device function shared with the
+// fused small-M tail of the global step).
 template <Layout LA, Layout LB>
 __global__ void __launch_bounds__(256, 1) gemm32_kernel(GemmP p) {
-  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (p.tri == 1 && bx > by) return;     // 32-tile granularity: every tile that touches the lower triangle is computed
-  if (p.tri == 2 && bx < by) return;
   __shared__ __attribute__((aligned(16))) double sA[SmallImg<LA>::DOUBLES];
   __shared__ __attribute__((aligned(16))) double sB[SmallImg<LB>::DOUBLES];
-  constexpr int LDA = SmallImg<LA>::LD, LDB = SmallImg<LB>::LD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = 16 * (wave >> 1), wc = 16 * (wave & 1);
-  const int lr = lane & 15, lk = lane >> 4, lj = lane & 3;
-  const int bi = bz % p.inner, bo = bz / p.inner;
-  const double* A = p.A + (long)bi * p.sA + (long)bo * p.oA;
-  const double* B = p.B + (long)bi * p.sB + (long)bo * p.oB;
-  double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
-  const long row0 = (long)by * ST, col0 = (long)bx * ST;
-  const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda : A + row0;
-  const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb : B + col0;
-  const long a_step = (LA == K_CONTIG) ? SKC : (long)SKC * p.lda;
-  const long b_step = (LB == K_CONTIG) ? SKC : (long)SKC * p.ldb;
-  const int nc = (p.K + SKC - 1) / SKC;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const unsigned aA = lds_byte_addr(sA) + 8u * (unsigned)(LA == K_CONTIG ? (wr + lr) * LDA + lk : lk * LDA + wr + lr);
-  const unsigned aB = lds_byte_addr(sB) + 8u * (unsigned)(LB == K_CONTIG ? (wc + lj) * LDB + lk : lk * LDB + wc + lj);
-  double2 ra[8], rb[8];
-  small_load<LA>(Ab, p.lda, p.K, tid, ra);
-  small_load<LB>(Bb, p.ldb, p.K, tid, rb);
-  for (int c = 0; c < nc; ++c) {
-    small_store<LA>(sA, tid, ra);
-    small_store<LB>(sB, tid, rb);
-    __syncthreads();
-    if (c + 1 < nc) {
-      small_load<LA>(Ab + (long)(c + 1) * a_step, p.lda, p.K - (c + 1) * SKC, tid, ra);
-      small_load<LB>(Bb + (long)(c + 1) * b_step, p.ldb, p.K - (c + 1) * SKC, tid, rb);
-    }
-    double a[2], b[2][4];
-    auto rd = [&](auto kc, double& av, double (&bv)[4]) {
-      constexpr int k4 = decltype(kc)::value;
-      av = ds_read64<(LA == K_CONTIG ? 4 * k4 : 4 * k4 * LDA) * 8>(aA);
-      static_for<0, 4>([&](auto jc) {
-        constexpr int bc = decltype(jc)::value;
-        bv[bc] = ds_read64<(LB == K_CONTIG ? 4 * bc * LDB + 4 * k4 : 4 * k4 * LDB + 4 * bc) * 8>(aB);
-      });
-    };
-    rd(IC<0>{}, a[0], b[0]);
-    static_for<0, SKC / 4>([&](auto kc) {
-      constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
-      if constexpr (k4 + 1 < SKC / 4) { rd(IC<k4 + 1>{}, a[cur ^ 1], b[cur ^ 1]); lgkm_wait<5>(); }
-      else lgkm_wait<0>();
-#pragma unroll
-      for (int bc = 0; bc < 4; ++bc) mfma444_acc(acc[bc], a[cur], b[cur][bc]);
-    });
-    __syncthreads();
-  }
-  mfma_drain(acc[3]);
-  acc_fence(acc);
-  const long r = row0 + wr + 4 * ((lane >> 2) & 3) + (lane >> 4);
-#pragma unroll
-  for (int bc = 0; bc < 4; ++bc) {
-    const long cc = col0 + wc + 4 * bc + lj;
-    C[r * p.ldc + cc] = p.alpha * acc[bc] + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
-  }
+  gemm32_tile<LA, LB>(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
 }
 
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int tiles_x, int tiles_y) {

@@ -183,6 +183,7 @@ struct gp_ctx {
   double* h_glob[2] = {nullptr, nullptr};
   hipEvent_t glob_ev[2] = {nullptr, nullptr};
   int glob_slot = 0;
+  double* h_out = nullptr;    // gp_finish: pinned, mapped [GS_COUNT + 8 | M*Q + Q] -- finish_kernel writes the evaluation's results straight into it
   // timing
   hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double t_ms[5] = {0, 0, 0, 0, 0};
@@ -223,6 +224,8 @@ void comm_free(gp_ctx* c);
 // linalg.hip
 int run_global_step(gp_ctx* c);
 int check_global(gp_ctx* c);
+// the same with the scalars + failure flags already on the host (h = [GS_COUNT + 8] doubles, or NULL when nothing is pending)
+int check_global_from(gp_ctx* c, const double* h);
 // PRECONDITION: the 128-blocks of Linv strictly above the block diagonal must be ZERO on entry -- they are never written here and
 // Inv = Linv^T Linv reads the whole matrix.  gp_create allocates Linv zeroed and nothing else writes those blocks; the test hook
 // gp_debug_potrf_inverse memsets its own buffer.  A caller that hands in a reused scratch buffer must clear it first.

@@ -7,6 +7,7 @@
 // and every trace unchanged.
 #include "gp_common.h"
 #include "potrf128.h"
+#include "gemm32.h"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -87,8 +88,11 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
 __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict__ Z, const double* __restrict__ alpha, double sf2,
                                                          double beta, const double* __restrict__ Psi2, int M, int Mp, int Q,
                                                          double* __restrict__ Kmm, double* __restrict__ A, double* __restrict__ Keep,
-                                                         double jitK, double jitA) {
+                                                         double jitK, double jitA, double* __restrict__ gs_zero) {
   const long total = (long)Mp * Mp;
+  // the global step's device scalars and failure flags start from zero (this used to be a hipMemsetAsync: a blit dispatch with ~10 us of idle
+  // stream around it); the panel kernels that write them are later launches
+  if (blockIdx.x == 0 && threadIdx.x < GS_COUNT + 8) gs_zero[threadIdx.x] = 0.0;
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
     const int i = (int)(idx / Mp), k = (int)(idx - (long)i * Mp);
     double v;
@@ -115,10 +119,32 @@ __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict
 // workgroup per row m: A[m][k] is wave-uniform, E[k][:] a coalesced row.  With float64 residuals the step is worthless (the residual IS the
 // rounding error); with this one the error of grad_Z against an 80-bit evaluation drops from 1.3e-5 to 7.5e-6 at N = 1e6.
 // `identity`: C = I (the residual of an inverse: refining P = A^-1 the same way was measured -- no change in grad_Z, +0.17 ms -- and is not done).
+// the double-double partial of row m, column d over k in [k0, k1): the chain every quarter of solve_residual_kernel runs (and the fused tail)
+__device__ __forceinline__ void residual_chain(const double* __restrict__ krow, const double* __restrict__ prow, const double* __restrict__ E, double beta,
+                                               double jitA, int m, int d, int Dp, int k0, int k1, double& hi, double& lo) {
+#pragma clang fp contract(off)   // the error-free transformations below must not be fused (hi + a e as one FMA breaks the two-sum)
+  hi = 0.0; lo = 0.0;
+#pragma unroll 8
+  for (int k = k0; k < k1; ++k) {
+    const double a = fma(beta, prow[k], krow[k]) + (k == m ? jitA : 0.0);
+    const double e = E[(long)k * Dp + d];
+    const double pr = a * e, pe = fma(a, e, -pr);           // a e = pr + pe exactly
+    const double t = hi + pr, bb = t - hi;                   // two-sum
+    lo += ((hi - (t - bb)) + (pr - bb)) + pe;
+    hi = t;
+  }
+}
+// (hi, lo) += (x, xl) in double-double
+__device__ __forceinline__ void residual_add(double& hi, double& lo, double x, double xl) {
+#pragma clang fp contract(off)
+  const double t = hi + x, bb = t - hi;
+  lo += ((hi - (t - bb)) + (x - bb)) + xl;
+  hi = t;
+}
 __global__ void __launch_bounds__(512) solve_residual_kernel(const double* __restrict__ Keep, const double* __restrict__ Psi2, double beta, double jitA,
                                                              const double* __restrict__ C, const double* __restrict__ E, int M, int Mp, int Dp,
                                                              double* __restrict__ R, int identity) {
-#pragma clang fp contract(off)   // the error-free transformations below must not be fused (hi + a e as one FMA breaks the two-sum)
+#pragma clang fp contract(off)
   // 128 columns x 4 quarters of the contraction range per workgroup: four waves per SIMD hide the latency of the E loads behind each other's
   // two-sum chains (one thread per column, 1024 waves in all: 44 us at M = 512).  The quarter is wave-uniform (readfirstlane), so A[m][k] stays a
   // scalar load.  The four double-double partials are added in order by the first quarter's thread.
@@ -130,32 +156,40 @@ __global__ void __launch_bounds__(512) solve_residual_kernel(const double* __res
   for (int d0 = 0; d0 < Dp; d0 += 128) {
     const int d = d0 + dl;
     double hi = 0.0, lo = 0.0;
-    if (d < Dp) {
-#pragma unroll 8
-      for (int k = k0; k < k1; ++k) {
-        const double a = fma(beta, prow[k], krow[k]) + (k == m ? jitA : 0.0);
-        const double e = E[(long)k * Dp + d];
-        const double pr = a * e, pe = fma(a, e, -pr);           // a e = pr + pe exactly
-        const double t = hi + pr, bb = t - hi;                   // two-sum
-        lo += ((hi - (t - bb)) + (pr - bb)) + pe;
-        hi = t;
-      }
-    }
+    if (d < Dp) residual_chain(krow, prow, E, beta, jitA, m, d, Dp, k0, k1, hi, lo);
     if (kq > 0) { ph[kq - 1][dl] = hi; pl[kq - 1][dl] = lo; }
     __syncthreads();
     if (kq == 0 && d < Dp) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double x = ph[j][dl];
-        const double t = hi + x, bb = t - hi;
-        lo += ((hi - (t - bb)) + (x - bb)) + pl[j][dl];
-        hi = t;
-      }
+      for (int j = 0; j < 3; ++j) residual_add(hi, lo, ph[j][dl], pl[j][dl]);
       const double c0 = identity ? (d == m ? 1.0 : 0.0) : C[(long)m * Dp + d];
       R[(long)m * Dp + d] = (c0 - hi) - lo;
     }
     __syncthreads();
   }
+}
+// the same row by a 256-thread workgroup (Dp = 128): thread (dl, h) runs quarters h + 2 and h one after the other -- the arithmetic of every quarter
+// and the order in which the four partials are added are those of solve_residual_kernel.  ph / pl: [3][128] doubles of LDS each.
+__device__ __forceinline__ void residual_row256(int m, const double* __restrict__ Keep, const double* __restrict__ Psi2, double beta, double jitA,
+                                                const double* __restrict__ C, const double* __restrict__ E, int M, int Mp, int Dp,
+                                                double* __restrict__ R, double (*ph)[128], double (*pl)[128]) {
+#pragma clang fp contract(off)
+  const int dl = threadIdx.x & 127, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+  const double* krow = Keep + (long)m * Mp;
+  const double* prow = Psi2 + (long)m * Mp;
+  const int kper = (M + 3) / 4;
+  double hi, lo, hi2, lo2;
+  { const int kq = h + 2, k0 = kq * kper, k1 = min(M, k0 + kper); residual_chain(krow, prow, E, beta, jitA, m, dl, Dp, k0, k1, hi2, lo2); }
+  { const int kq = h, k0 = kq * kper, k1 = min(M, k0 + kper); residual_chain(krow, prow, E, beta, jitA, m, dl, Dp, k0, k1, hi, lo); }
+  ph[h + 1][dl] = hi2; pl[h + 1][dl] = lo2;          // quarters 2 and 3 -> slots 1 and 2
+  if (h == 1) { ph[0][dl] = hi; pl[0][dl] = lo; }    // quarter 1 -> slot 0
+  __syncthreads();
+  if (h == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) residual_add(hi, lo, ph[j][dl], pl[j][dl]);
+    R[(long)m * Dp + dl] = (C[(long)m * Dp + dl] - hi) - lo;
+  }
+  __syncthreads();
 }
 
 // C = A B with the products error-free (FMA) and the sums carried in double-double (two-sum), rounded to double once at the end.
@@ -168,12 +202,12 @@ __global__ void __launch_bounds__(512) solve_residual_kernel(const double* __res
 // no Newton step, no double-double storage is needed.  1024 waves at M = 512 with RB = 4; the four waves of a workgroup share their column
 // block, so B's rows are read from L2 once per workgroup.
 template <int RB, int KU>
-__global__ void __launch_bounds__(256) ddacc_gemm_kernel(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int K,
-                                                          double* __restrict__ C, long ldc) {
+__device__ __forceinline__ void ddacc_block(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int K,
+                                            double* __restrict__ C, long ldc, int vbx, int vby) {
 #pragma clang fp contract(off)   // hi + a b as one FMA would break the two-sum
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x * 64 + lane;
-  const int i0 = (blockIdx.y * 4 + wave) * RB;
+  const int j = vbx * 64 + lane;
+  const int i0 = (vby * 4 + wave) * RB;
   double hi[RB], lo[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) { hi[r] = 0.0; lo[r] = 0.0; }
@@ -198,18 +232,23 @@ __global__ void __launch_bounds__(256) ddacc_gemm_kernel(const double* __restric
 #pragma unroll
   for (int r = 0; r < RB; ++r) C[(long)(i0 + r) * ldc + j] = hi[r] + lo[r];
 }
+template <int RB, int KU>
+__global__ void __launch_bounds__(256) ddacc_gemm_kernel(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int K,
+                                                          double* __restrict__ C, long ldc) {
+  ddacc_block<RB, KU>(A, lda, B, ldb, K, C, ldc, blockIdx.x, blockIdx.y);
+}
 
 // sum over the M x M (or M x D) block of x o y; one block per pair, results into out[slot]
 struct DotJob { const double* x; const double* y; long ld; int rows, cols; int slot; };
 struct DotJobs { DotJob j[8]; int n; };
 constexpr int DOT_BLOCKS = 64;
-__global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* part) {
-  // grid (DOT_BLOCKS, jobs): per-block partial sums part[job][block]; scalars_kernel adds them in a fixed order, so the bound is
+// virtual block (vbx of DOT_BLOCKS, job vby) by the calling 256-thread workgroup; red: 256 doubles of LDS
+__device__ __forceinline__ void dots_block(const DotJobs& jobs, double* part, int vbx, int vby, double* red) {
+  // per-block partial sums part[job][block]; scalars_kernel adds them in a fixed order, so the bound is
   // bit-identical from run to run (an atomicAdd here made the last bits of F depend on the block schedule)
-  __shared__ double red[256];
-  const DotJob jb = jobs.j[blockIdx.y];
+  const DotJob jb = jobs.j[vby];
   double s = 0.0;
-  for (int r = blockIdx.x; r < jb.rows; r += gridDim.x)
+  for (int r = vbx; r < jb.rows; r += DOT_BLOCKS)
     for (int c = threadIdx.x; c < jb.cols; c += 256) s += jb.x[(long)r * jb.ld + c] * jb.y[(long)r * jb.ld + c];
   red[threadIdx.x] = s;
   __syncthreads();
@@ -217,36 +256,47 @@ __global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* part) {
     if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.y * DOT_BLOCKS + blockIdx.x] = red[0];
+  if (threadIdx.x == 0) part[vby * DOT_BLOCKS + vbx] = red[0];
+  __syncthreads();
+}
+__global__ void __launch_bounds__(256) dots_kernel(DotJobs jobs, double* part) {
+  // grid (DOT_BLOCKS, jobs)
+  __shared__ double red[256];
+  dots_block(jobs, part, blockIdx.x, blockIdx.y, red);
 }
 
 // Bbar, dF/dKmm, Abar and the phase-2 operand Bm = [2 Bbar ; Abar^T]
+__device__ __forceinline__ void assemble_elem(long idx, const double* __restrict__ Ki, const double* __restrict__ P, const double* __restrict__ EEt,
+                                              const double* __restrict__ KPK, const double* __restrict__ E, double beta, double Dd, int Mp, int Dp,
+                                              double* __restrict__ Bbar, double* __restrict__ dFdK, double* __restrict__ Abar, double* __restrict__ Bm) {
+  const long mm = (long)Mp * Mp;
+  if (idx < mm) {
+    const double kp = Ki[idx] - P[idx];
+    const double b = 0.5 * beta * Dd * kp - 0.5 * beta * beta * beta * EEt[idx];
+    Bbar[idx] = b;
+    dFdK[idx] = 0.5 * Dd * kp - 0.5 * beta * Dd * KPK[idx] - 0.5 * beta * beta * EEt[idx];
+    Bm[idx] = 2.0 * b;
+  } else {
+    const long e = idx - mm;
+    const long m = e / Dp, d = e - m * Dp;
+    const double a = beta * beta * E[e];
+    Abar[e] = a;
+    Bm[mm + d * Mp + m] = a;
+  }
+}
 __global__ void __launch_bounds__(256) assemble_kernel(const double* __restrict__ Ki, const double* __restrict__ P,
                                                         const double* __restrict__ EEt, const double* __restrict__ KPK,
                                                         const double* __restrict__ E, double beta, double Dd, int Mp, int Dp,
                                                         double* __restrict__ Bbar, double* __restrict__ dFdK, double* __restrict__ Abar,
                                                         double* __restrict__ Bm) {
   const long mm = (long)Mp * Mp, md = (long)Mp * Dp;
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < mm + md; idx += (long)gridDim.x * 256L) {
-    if (idx < mm) {
-      const double kp = Ki[idx] - P[idx];
-      const double b = 0.5 * beta * Dd * kp - 0.5 * beta * beta * beta * EEt[idx];
-      Bbar[idx] = b;
-      dFdK[idx] = 0.5 * Dd * kp - 0.5 * beta * Dd * KPK[idx] - 0.5 * beta * beta * EEt[idx];
-      Bm[idx] = 2.0 * b;
-    } else {
-      const long e = idx - mm;
-      const long m = e / Dp, d = e - m * Dp;
-      const double a = beta * beta * E[e];
-      Abar[e] = a;
-      Bm[mm + d * Mp + m] = a;
-    }
-  }
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < mm + md; idx += (long)gridDim.x * 256L)
+    assemble_elem(idx, Ki, P, EEt, KPK, E, beta, Dd, Mp, Dp, Bbar, dFdK, Abar, Bm);
 }
 
 // F, grad_beta, grad_sf2 from the traces (partial_terms.py:464-472, 346-358, 322-333)
-__global__ void scalars_kernel(const double* sc, double* gs, DotJobs jobs, const double* part, double beta, double sf2, double Dd, double Nglob) {
-  if (blockIdx.x != 0) return;
+__device__ __forceinline__ void scalars_block(const double* sc, double* gs, const DotJobs& jobs, const double* part, double beta, double sf2, double Dd,
+                                              double Nglob) {
   if (threadIdx.x < jobs.n) {
     double s = 0.0;
     for (int b = 0; b < DOT_BLOCKS; ++b) s += part[threadIdx.x * DOT_BLOCKS + b];
@@ -264,36 +314,40 @@ __global__ void scalars_kernel(const double* sc, double* gs, DotJobs jobs, const
                      0.5 * beta * beta * trEPE;
   gs[GS_GRAD_SF2] = (gs[GS_SUM_V] + gs[GS_SUM_AC] + 2.0 * gs[GS_SUM_BPSI2] + (-0.5 * beta * Dd) * Psi0) / sf2;
 }
+__global__ void scalars_kernel(const double* sc, double* gs, DotJobs jobs, const double* part, double beta, double sf2, double Dd, double Nglob) {
+  if (blockIdx.x != 0) return;
+  scalars_block(sc, gs, jobs, part, beta, sf2, Dd, Nglob);
+}
 
-// Kmm-dependent parts: gK[j*Q+k] = -alpha_k sum_m' (dFdK+dFdK^T)[j,m'] Kmm[j,m'] (z_jk - z_m'k)
-//                      gK[M*Q+q] = sum_mm' (-1/2 dFdK o Kmm [- 1/4 Bbar o Psi2 if !regimeA]) (z_mq - z_m'q)^2
-// one block per row j; alpha parts are accumulated per block into gKpart[j][Q] and summed by the caller's reduce
-__global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict__ dFdK, const double* __restrict__ Kmm,
-                                                         const double* __restrict__ Bbar, const double* __restrict__ Psi2,
-                                                         const double* __restrict__ Z, const double* __restrict__ alpha, int M, int Mp,
-                                                         int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart) {
+// row j by 128 threads (tid 0..127: two waves); red: 2 * QC doubles of LDS owned by these 128 threads.  `active` false: the threads only keep the
+// workgroup barriers in step (the fused tail runs two rows per 256-thread workgroup, and the last pair may be half empty).
+constexpr int KG_QC = 8;
+__device__ __forceinline__ void kmm_grads_row(int j, bool active, int tid, double* red, const double* __restrict__ dFdK, const double* __restrict__ Kmm,
+                                              const double* __restrict__ Bbar, const double* __restrict__ Psi2, const double* __restrict__ Z,
+                                              const double* __restrict__ alpha, int M, int Mp, int Q, int regimeA, double* __restrict__ gZ,
+                                              double* __restrict__ gapart) {
   // latent dimensions in chunks of 8: the sums of a chunk stay in registers over the row, then one butterfly per sum and one
   // LDS hand-over between the two waves (the first version ran two 7-step workgroup reductions per latent dimension)
-  constexpr int QC = 8;
-  __shared__ double red[2 * QC];
-  const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int QC = KG_QC;
+  const int lane = tid & 63, wave = tid >> 6;
   for (int q0 = 0; q0 < Q; q0 += QC) {
     double sz[QC], sa[QC], zj[QC];
 #pragma unroll
-    for (int u = 0; u < QC; ++u) { sz[u] = 0.0; sa[u] = 0.0; zj[u] = (q0 + u < Q) ? Z[(long)j * Q + q0 + u] : 0.0; }
-    for (int m = threadIdx.x; m < M; m += 128) {
-      const double k = Kmm[(long)j * Mp + m];
-      const double fjm = dFdK[(long)j * Mp + m];
-      const double sym = (fjm + dFdK[(long)m * Mp + j]) * k;
-      double w = -0.5 * fjm * k;
-      if (!regimeA) w += -0.25 * Bbar[(long)j * Mp + m] * Psi2[(long)j * Mp + m];
+    for (int u = 0; u < QC; ++u) { sz[u] = 0.0; sa[u] = 0.0; zj[u] = (active && q0 + u < Q) ? Z[(long)j * Q + q0 + u] : 0.0; }
+    if (active)
+      for (int m = tid; m < M; m += 128) {
+        const double k = Kmm[(long)j * Mp + m];
+        const double fjm = dFdK[(long)j * Mp + m];
+        const double sym = (fjm + dFdK[(long)m * Mp + j]) * k;
+        double w = -0.5 * fjm * k;
+        if (!regimeA) w += -0.25 * Bbar[(long)j * Mp + m] * Psi2[(long)j * Mp + m];
 #pragma unroll
-      for (int u = 0; u < QC; ++u) {
-        const double dz = zj[u] - ((q0 + u < Q) ? Z[(long)m * Q + q0 + u] : 0.0);
-        sz[u] = fma(sym, dz, sz[u]);
-        sa[u] = fma(w * dz, dz, sa[u]);
+        for (int u = 0; u < QC; ++u) {
+          const double dz = zj[u] - ((q0 + u < Q) ? Z[(long)m * Q + q0 + u] : 0.0);
+          sz[u] = fma(sym, dz, sz[u]);
+          sa[u] = fma(w * dz, dz, sa[u]);
+        }
       }
-    }
 #pragma unroll
     for (int u = 0; u < QC; ++u)
       for (int sh = 32; sh > 0; sh >>= 1) { sz[u] += __shfl_xor(sz[u], sh); sa[u] += __shfl_xor(sa[u], sh); }
@@ -302,7 +356,7 @@ __global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict
       for (int u = 0; u < QC; ++u) { red[u] = sz[u]; red[QC + u] = sa[u]; }
     }
     __syncthreads();
-    if (wave == 0 && lane == 0) {
+    if (active && wave == 0 && lane == 0) {
 #pragma unroll
       for (int u = 0; u < QC; ++u)
         if (q0 + u < Q) {
@@ -313,16 +367,158 @@ __global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(256) colsum_kernel(const double* __restrict__ part, int rows, int Q, double* __restrict__ out) {
-  __shared__ double red[256];
-  const int q = blockIdx.x;
+// Kmm-dependent parts: gK[j*Q+k] = -alpha_k sum_m' (dFdK+dFdK^T)[j,m'] Kmm[j,m'] (z_jk - z_m'k)
+//                      gK[M*Q+q] = sum_mm' (-1/2 dFdK o Kmm [- 1/4 Bbar o Psi2 if !regimeA]) (z_mq - z_m'q)^2
+// one block per row j; alpha parts are accumulated per block into gKpart[j][Q] and summed by the caller's reduce
+__global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict__ dFdK, const double* __restrict__ Kmm,
+                                                         const double* __restrict__ Bbar, const double* __restrict__ Psi2,
+                                                         const double* __restrict__ Z, const double* __restrict__ alpha, int M, int Mp,
+                                                         int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart) {
+  __shared__ double red[2 * KG_QC];
+  kmm_grads_row(blockIdx.x, true, threadIdx.x, red, dFdK, Kmm, Bbar, Psi2, Z, alpha, M, Mp, Q, regimeA, gZ, gapart);
+}
+// column q of part [rows][Q] summed by the calling 256-thread workgroup; red: 256 doubles of LDS
+__device__ __forceinline__ void colsum_block(const double* __restrict__ part, int rows, int Q, double* __restrict__ out, int q, double* red) {
   double s = 0.0;
   for (int r = threadIdx.x; r < rows; r += 256) s += part[(long)r * Q + q];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
   if (threadIdx.x == 0) out[q] = red[0];
+  __syncthreads();
 }
+__global__ void __launch_bounds__(256) colsum_kernel(const double* __restrict__ part, int rows, int Q, double* __restrict__ out) {
+  __shared__ double red[256];
+  colsum_block(part, rows, Q, out, blockIdx.x, red);
+}
+
+// ---------------------------------------------------------------------------------------------- fused tail for one-panel problems
+// M <= 128 and D <= 128 (BASELINE configs[1]: M = 128, D = 10): everything of the global step behind the panel factorisation -- the two inverses,
+// E with its refinement step, Psi2 E, E E^T, K_mm^-1 Psi2 in double-double, its product with K_mm^-1, the assembled partials, the seven traces, the
+// scalars and the K_mm parts of the gradients -- used to be FIFTEEN launches of 4-12 us each, every one of them at the launch floor
+// (profiles/r05_config1_timeline.txt: 80 us for 2e7 flop).  Here they are the eight stages of ONE persistent kernel: 64 workgroups walk each stage's
+// work items (the same 32 x 32 tile products, double-double blocks, dot-product blocks and rows as the separate kernels: the device functions above
+// are shared, so the results are bit-identical), with an agent-scope barrier between stages.
+//   barrier: one counter (zeroed by build_kmm_kernel with the other scalars of the step); a workgroup's thread 0 releases (L2 write-back: the
+//   workgroups sit on eight XCDs with separate L2s), adds 1, spins until the count reaches 64 x stage, acquires (L1 / L2 invalidate); the scalar
+//   cache is invalidated by every wave (ddacc_block and residual_chain read rows that earlier stages wrote through scalar loads).
+// All 64 workgroups are resident at once (one per CU, 98 KB of LDS), which the spin needs; the stream's previous kernel has finished by then.
+constexpr int TAIL_WGS = 64;
+constexpr int TAIL_LDS_DOUBLES = 2 * SmallImg<FREE_CONTIG>::DOUBLES;     // the larger operand image, twice (12288 doubles = 96 KB)
+struct TailP {
+  const double* Linv; double* Inv;                    // [2][128][128]
+  const double* Psi2; const double* C; const double* sc; const double* Keep;
+  double *E, *PsiE, *T1, *T2, *dFdK, *Bbar, *Abar, *Bm;
+  const double* Z; const double* alpha;
+  double* gs; double* gK; unsigned* bar;
+  DotJobs jobs;
+  double beta, sf2, Dd, Nglob, jitA;
+  int M, Q, regimeA, refine, dd;
+};
+__device__ __forceinline__ void tail_barrier(unsigned* bar, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();                                                   // release: this workgroup's stores reach memory
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __threadfence();                                                   // acquire: later loads of this CU see the other workgroups' stores
+  }
+  __syncthreads();
+  __builtin_amdgcn_s_dcache_inv();
+}
+__global__ void __launch_bounds__(256, 1) gs_tail128_kernel(TailP p) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* sA = sm;
+  double* sB = sm + SmallImg<FREE_CONTIG>::DOUBLES;
+  double* red = sm;                                     // the stages without tile products reuse the front of the images
+  constexpr int Mp = 128, Dp = 128;
+  constexpr long mm = (long)Mp * Mp;
+  const int wg = blockIdx.x;
+  unsigned stage = 0;
+  double* Ki = p.Inv;
+  double* P = p.Inv + mm;
+  GemmP g;
+  g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
+  // S1: [Ki ; P] = X^T X for both factors (32 tiles)
+  {
+    GemmP r = g;
+    r.A = p.Linv; r.lda = Mp; r.sA = mm; r.B = p.Linv; r.ldb = Mp; r.sB = mm; r.C = p.Inv; r.ldc = Mp; r.sC = mm; r.K = Mp;
+    for (int t = wg; t < 32; t += TAIL_WGS) gemm32_tile<FREE_CONTIG, FREE_CONTIG>(r, t & 3, (t >> 2) & 3, t >> 4, sA, sB);
+  }
+  tail_barrier(p.bar, TAIL_WGS * ++stage);
+  // S2: E = P C (16 tiles)  |  T2 = Ki Psi2, accumulated in double-double (32 blocks) or on the matrix core (16 tiles)
+  {
+    GemmP e = g;
+    e.K = Mp; e.A = P; e.lda = Mp; e.B = p.C; e.ldb = Dp; e.C = p.E; e.ldc = Dp;
+    GemmP k = g;
+    k.K = Mp; k.A = Ki; k.lda = Mp; k.B = p.Psi2; k.ldb = Mp; k.C = p.T2; k.ldc = Mp;
+    const int n2 = p.dd ? 32 : 16;
+    for (int t = wg; t < 16 + n2; t += TAIL_WGS) {
+      if (t < 16) gemm32_tile<K_CONTIG, FREE_CONTIG>(e, t & 3, t >> 2, 0, sA, sB);
+      else if (p.dd) ddacc_block<2, 8>(Ki, (long)Mp, p.Psi2, (long)Mp, Mp, p.T2, (long)Mp, (t - 16) & 1, (t - 16) >> 1);
+      else gemm32_tile<K_CONTIG, FREE_CONTIG>(k, (t - 16) & 3, (t - 16) >> 2, 0, sA, sB);
+    }
+  }
+  tail_barrier(p.bar, TAIL_WGS * ++stage);
+  // S3: dFdK(tmp) = T2 Ki (16 tiles)  |  R = C - A E in double-double, one row per item, into PsiE (rows >= M: zero)
+  {
+    GemmP k = g;
+    k.K = Mp; k.A = p.T2; k.lda = Mp; k.B = Ki; k.ldb = Mp; k.C = p.dFdK; k.ldc = Mp;
+    const int nrows = p.refine ? Mp : 0;
+    double (*ph)[128] = reinterpret_cast<double (*)[128]>(red);
+    double (*pl)[128] = reinterpret_cast<double (*)[128]>(red + 3 * 128);
+    for (int t = wg; t < 16 + nrows; t += TAIL_WGS) {
+      if (t < 16) gemm32_tile<K_CONTIG, FREE_CONTIG>(k, t & 3, t >> 2, 0, sA, sB);
+      else {
+        const int m = t - 16;
+        if (m < p.M) residual_row256(m, p.Keep, p.Psi2, p.beta, p.jitA, p.C, p.E, p.M, Mp, Dp, p.PsiE, ph, pl);
+        else if (threadIdx.x < Dp) p.PsiE[(long)m * Dp + threadIdx.x] = 0.0;
+      }
+    }
+  }
+  tail_barrier(p.bar, TAIL_WGS * ++stage);
+  // S4: E += P R
+  if (p.refine) {
+    GemmP e = g;
+    e.K = Mp; e.A = P; e.lda = Mp; e.B = p.PsiE; e.ldb = Dp; e.C = p.E; e.ldc = Dp; e.beta = 1.0;
+    for (int t = wg; t < 16; t += TAIL_WGS) gemm32_tile<K_CONTIG, FREE_CONTIG>(e, t & 3, t >> 2, 0, sA, sB);
+    tail_barrier(p.bar, TAIL_WGS * ++stage);
+  }
+  // S5: PsiE = Psi2 E (16 tiles)  |  T1 = E E^T (16 tiles)
+  {
+    GemmP a = g;
+    a.K = Mp; a.A = p.Psi2; a.lda = Mp; a.B = p.E; a.ldb = Dp; a.C = p.PsiE; a.ldc = Dp;
+    GemmP b = g;
+    b.K = Dp; b.A = p.E; b.lda = Dp; b.B = p.E; b.ldb = Dp; b.C = p.T1; b.ldc = Mp;
+    for (int t = wg; t < 32; t += TAIL_WGS) {
+      if (t < 16) gemm32_tile<K_CONTIG, FREE_CONTIG>(a, t & 3, t >> 2, 0, sA, sB);
+      else gemm32_tile<K_CONTIG, K_CONTIG>(b, (t - 16) & 3, (t - 16) >> 2, 0, sA, sB);
+    }
+  }
+  tail_barrier(p.bar, TAIL_WGS * ++stage);
+  // S6: the assembled partials and the phase-2 operand
+  for (long idx = wg * 256L + threadIdx.x; idx < mm + (long)Mp * Dp; idx += TAIL_WGS * 256L)
+    assemble_elem(idx, Ki, P, p.T1, p.dFdK, p.E, p.beta, p.Dd, Mp, Dp, p.Bbar, p.dFdK, p.Abar, p.Bm);
+  tail_barrier(p.bar, TAIL_WGS * ++stage);
+  // S7: the seven traces (jobs x 64 blocks)  |  K_mm parts of grad_Z / grad_alpha, two rows per pass (alpha partials per row through T2)
+  {
+    double* dpart = p.gs + GS_COUNT + 8;
+    const int nd = p.jobs.n * DOT_BLOCKS, nk = (p.M + 1) / 2;
+    for (int t = wg; t < nd + nk; t += TAIL_WGS) {
+      if (t < nd) dots_block(p.jobs, dpart, t % DOT_BLOCKS, t / DOT_BLOCKS, red);
+      else {
+        const int half = threadIdx.x >> 7, j = 2 * (t - nd) + half;
+        kmm_grads_row(j, j < p.M, threadIdx.x & 127, red + 2 * KG_QC * half, p.dFdK, p.Keep, p.Bbar, p.Psi2, p.Z, p.alpha, p.M, Mp, p.Q, p.regimeA,
+                      p.gK, p.T2);
+      }
+    }
+  }
+  tail_barrier(p.bar, TAIL_WGS * ++stage);
+  // S8: F, grad_beta, grad_sf2  |  column sums of the alpha partials
+  if (wg == 0) scalars_block(p.sc, p.gs, p.jobs, p.gs + GS_COUNT + 8, p.beta, p.sf2, p.Dd, p.Nglob);
+  else for (int q = wg - 1; q < p.Q; q += TAIL_WGS - 1) colsum_block(p.T2, p.M, p.Q, p.gK + (long)p.M * p.Q, q, red);
+}
+std::atomic<int> g_opt_gs_tail{env_on("GPARML_GS_TAIL") ? 1 : 0};
 
 // Host side of the global step's outcome: one D2H of the scalars + failure flags, at the first call that needs them
 // (gp_global_status, gp_finish, gp_download).  Returns GP_OK, GP_ERR_NOT_PD, GP_ERR_NON_FINITE or GP_RETRY_JITTER.
@@ -331,6 +527,13 @@ int check_global(gp_ctx* c) {
     double h[GS_COUNT + 8];
     GP_HIP(c, hipMemcpyAsync(h, c->gs, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     GP_HIP(c, hipStreamSynchronize(c->stream));
+    return check_global_from(c, h);
+  }
+  return check_global_from(c, nullptr);
+}
+
+int check_global_from(gp_ctx* c, const double* h) {
+  if (c->gs_pending && h) {
     for (int i = 0; i < GS_COUNT; ++i) c->h_gs[i] = h[i];
     c->gs_pending = false;
     const int failed = (h[GS_COUNT] != 0.0 ? 1 : 0) | (h[GS_COUNT + 1] != 0.0 ? 2 : 0);
@@ -365,12 +568,36 @@ int run_global_step(gp_ctx* c) {
   double* Psi2 = c->stats;
   double* C = c->stats + mm;
   double* sc = c->stats + mm + (long)Mp * Dp;
-  GP_HIP(c, hipMemsetAsync(c->gs, 0, (GS_COUNT + 8) * sizeof(double), st));
   c->gs_status = GP_OK;
   double* failf = c->gs + GS_COUNT;  // [2]
   hipLaunchKernelGGL(build_kmm_kernel, dim3(1024), dim3(256), 0, st, c->Z, c->alpha, c->sf2, c->beta, Psi2, M, Mp, Q, c->Kmm, c->Kmm + mm,
-                     c->KmmKeep, (c->jitter_mask & 1) ? 1e-7 : 0.0, (c->jitter_mask & 2) ? 1e-7 : 0.0);
+                     c->KmmKeep, (c->jitter_mask & 1) ? 1e-7 : 0.0, (c->jitter_mask & 2) ? 1e-7 : 0.0, c->gs);
   GP_HIP(c, hipGetLastError());
+  // one-panel problems (M, D <= 128): the panel kernel, then everything else in one persistent launch (gs_tail128_kernel)
+  if (Mp == NB && Dp == NB && g_opt_gs_tail.load()) {
+    GP_HIP(c, hipFuncSetAttribute((const void*)potrf_trinv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_DOUBLES * 8));
+    GP_HIP(c, hipFuncSetAttribute((const void*)gs_tail128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_DOUBLES * 8));
+    hipLaunchKernelGGL(potrf_trinv128_kernel, dim3(2), dim3(512), POTRF_LDS_DOUBLES * 8, st, c->Kmm, (long)Mp, mm, 0, c->Linv, failf, c->gs + GS_LOGDET_K);
+    TailP t;
+    t.Linv = c->Linv; t.Inv = c->Inv; t.Psi2 = Psi2; t.C = C; t.sc = sc; t.Keep = c->KmmKeep;
+    t.E = c->E; t.PsiE = c->PsiE; t.T1 = c->T1; t.T2 = c->T2; t.dFdK = c->dFdK; t.Bbar = c->Bbar; t.Abar = c->Abar; t.Bm = c->Bm;
+    t.Z = c->Z; t.alpha = c->alpha; t.gs = c->gs; t.gK = c->gK;
+    t.bar = reinterpret_cast<unsigned*>(c->gs + GS_COUNT + 4);     // a spare failure-flag slot: zeroed by build_kmm_kernel above
+    t.beta = c->beta; t.sf2 = c->sf2; t.Dd = (double)D; t.Nglob = (double)c->N_global; t.jitA = (c->jitter_mask & 2) ? 1e-7 : 0.0;
+    t.M = M; t.Q = Q; t.regimeA = c->regime_A ? 1 : 0; t.refine = g_opt_refine_E.load(); t.dd = g_opt_dd_kipsi2.load();
+    t.jobs.n = 7;
+    t.jobs.j[0] = {c->Inv, Psi2, Mp, M, M, GS_TR_KIPSI2};
+    t.jobs.j[1] = {c->Inv + mm, Psi2, Mp, M, M, GS_TR_PPSI2};
+    t.jobs.j[2] = {C, c->E, Dp, M, D, GS_TR_CE};
+    t.jobs.j[3] = {c->E, c->PsiE, Dp, M, D, GS_TR_EPSI2E};
+    t.jobs.j[4] = {c->dFdK, c->KmmKeep, Mp, M, M, GS_SUM_V};
+    t.jobs.j[5] = {c->Abar, C, Dp, M, D, GS_SUM_AC};
+    t.jobs.j[6] = {c->Bbar, Psi2, Mp, M, M, GS_SUM_BPSI2};
+    hipLaunchKernelGGL(gs_tail128_kernel, dim3(TAIL_WGS), dim3(256), TAIL_LDS_DOUBLES * 8, st, t);
+    GP_HIP(c, hipGetLastError());
+    c->gs_pending = true;
+    return GP_OK;
+  }
   // factorise [Kmm ; A] in place, invert.  T1 is the 2 x 128 x Mp work panel.
   // split-k workspace: the phase-1 partial buffer is free during the global step (>= 600 tiles)
   double* ws = ((size_t)2 * (Mp / TILE) * std::max(Mp, Dp) / TILE * kSplitK * TILE * TILE <= c->part_doubles) ? c->part : nullptr;
@@ -463,7 +690,8 @@ extern "C" int gp_debug_set_option(const char* name, int value) {
   if (!std::strcmp(name, "dd_kipsi2")) { g_opt_dd_kipsi2.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "refine_E")) { g_opt_refine_E.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "p1_i8")) { g_opt_p1_i8.store(value ? 1 : 0); return GP_OK; }
-  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8)", name);
+  if (!std::strcmp(name, "gs_tail")) { g_opt_gs_tail.store(value ? 1 : 0); return GP_OK; }
+  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, gs_tail)", name);
 }
 
 extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet) {

@@ -207,7 +207,11 @@ __global__ void __launch_bounds__(512, 4) p1v2_kernel(P1v2Args p) {
 //   out tile descriptor: kind 0 F (ti < tj), 1 diagonal tile ti (valid where col >= row), 2 C row-tile ti (valid columns < ncols)
 struct P1Out { int kind, ti, tj, first, nslices, stride, ncols, pad; };
 __global__ void __launch_bounds__(256) p1v2_reduce_kernel(const double* __restrict__ part, const P1Out* __restrict__ outs,
-                                                          double* __restrict__ Psi2, double* __restrict__ C, int Mp, int Dp) {
+                                                          double* __restrict__ Psi2, double* __restrict__ C, int Mp, int Dp,
+                                                          double sumYY, double psi0, double nlocal, double* __restrict__ sc) {
+  // the scalars of the statistics buffer (regime A: constants of the shard and sf2; p1_scalars_kernel's job, folded in here)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < SC_COUNT)
+    sc[threadIdx.x] = threadIdx.x == SC_SUM_YYT ? sumYY : threadIdx.x == SC_PSI0 ? psi0 : threadIdx.x == SC_NLOCAL ? nlocal : 0.0;
   const P1Out o = outs[blockIdx.y];
   const int e = blockIdx.x * 256 + threadIdx.x;   // element of the 128x128 tile
   const int r = e >> 7, c = e & 127;
@@ -334,7 +338,8 @@ int run_phase1_v2(gp_ctx* c) {
   GP_HIP(c, hipGetLastError());
   double* Psi2 = c->stats;
   double* C = c->stats + (long)c->Mp * c->Mp;
-  hipLaunchKernelGGL(p1v2_reduce_kernel, dim3(TILE * TILE / 256, pl->nouts), dim3(256), 0, c->stream, c->part, pl->outs, Psi2, C, c->Mp, c->Dp);
+  hipLaunchKernelGGL(p1v2_reduce_kernel, dim3(TILE * TILE / 256, pl->nouts), dim3(256), 0, c->stream, c->part, pl->outs, Psi2, C, c->Mp, c->Dp,
+                     c->sumYY, c->sf2 * (double)c->N, (double)c->N, C + (long)c->Mp * c->Dp);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }

@@ -566,12 +566,8 @@ int run_phase1(gp_ctx* c) {
   }
   if (p1v2_applicable(c)) {
     // fixed embeddings / sparse GP: the decomposition without wasted tile slots (p1v2.hip)
-    int rc = run_phase1_v2(c);
-    if (rc != GP_OK) return rc;
-    hipLaunchKernelGGL(p1_scalars_kernel, dim3(1), dim3(256), 0, c->stream, c->klpart, c->kl_blocks, c->sumYY, c->sf2, (double)c->N,
-                       1, c->stats + (long)c->Mp * c->Mp + (long)c->Mp * c->Dp);
-    GP_HIP(c, hipGetLastError());
-    return GP_OK;
+    // (the four scalars of regime A -- sum_YYT, Psi0 = sf2 N, KL = 0, n -- are written by p1v2_reduce_kernel: one launch less)
+    return run_phase1_v2(c);
   }
   const int mt = c->Mp / TILE;
   // regime A: Psi2 = Psi1^T Psi1 and C tiles; regime B: only the C tiles here (Psi2 comes from the pair kernel)
@@ -681,9 +677,14 @@ template <int NRB>
 __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
   const int slice = xcd + 8 * (bi / p.MT), mt = bi % p.MT;
-  if (slice >= p.S) return;
-  __shared__ __attribute__((aligned(16))) double lds[P2W8_LDS];
   constexpr int XS = 4 * NRB;
+  if (slice >= p.S) {
+    // a block past the last slice: its eight rows of the mu^2 partials are read by colsum2_kernel and must be zero (this replaces a
+    // hipMemsetAsync of the whole array in front of every launch: a blit dispatch with ~15 us of idle stream around it)
+    if (threadIdx.x < 8 * XS) p.gapart[(long)blockIdx.x * 8 * XS + threadIdx.x] = 0.0;
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) double lds[P2W8_LDS];
   static_assert(4096 + TILE * XS <= 4608 + 1024, "Xa tile does not fit next to slab set A");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Static priority for the second-dispatched half of the workgroup: with both halves at priority 0 the younger waves lose the VALU / LDS
@@ -1317,7 +1318,7 @@ int run_phase2(gp_ctx* c) {
 #endif
   if (fast) {                                        // nrb <= 3
     p.gapart = c->hgpart;
-    GP_HIP(c, hipMemsetAsync(c->hgpart, 0, (size_t)blocks * 8 * 4 * nrb * sizeof(double), c->stream));   // blocks past the last slice exit early
+    // (blocks past the last slice zero their own rows of hgpart)
     switch (nrb) {
       case 1: hipLaunchKernelGGL((p2_fast8_kernel<1>), dim3(blocks), dim3(512), 0, c->stream, p); break;
       case 2: hipLaunchKernelGGL((p2_fast8_kernel<2>), dim3(blocks), dim3(512), 0, c->stream, p); break;

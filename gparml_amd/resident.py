@@ -38,6 +38,9 @@ class ResidentModel(object):
 
     @staticmethod
     def _dist_ready():
+        import sys
+        if 'torch.distributed' not in sys.modules:     # nobody in this process can have initialised a group: do not pay the torch import
+            return False
         try:
             import torch.distributed as dist
             return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -53,7 +56,9 @@ class ResidentModel(object):
         if self._dist is None:
             return values
         import torch
-        t = torch.tensor(values, dtype=torch.float64, device='cuda' if self._dist.get_backend() == 'nccl' else 'cpu')
+        # the engine's own GPU, not torch's current device (a caller need not have run torch.cuda.set_device)
+        t = torch.tensor(values, dtype=torch.float64,
+                         device=torch.device('cuda', self.engines[0].device) if self._dist.get_backend() == 'nccl' else 'cpu')
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == 'sum' else self._dist.ReduceOp.MAX, group=self.group)
         self.n_collectives += 1
         return t.cpu().numpy()

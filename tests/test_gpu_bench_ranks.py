@@ -47,6 +47,85 @@ def _launch(tmp_path, name, text, world, timeout):
     return res
 
 
+RCCL_SCRIPT = r"""
+import os, socket, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+from gparml_amd.dist import DistributedEvaluator
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+import numpy as np
+s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1)
+N, D, M, Q = 500, 6, 40, 4
+d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=3, zseed=4, alpha_value=0.4)
+ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=False)
+for native in ('1', '0'):       # gp_allreduce inside the library, then torch.distributed on zero-copy views of the library's buffers
+    os.environ['GPARML_NATIVE_ALLREDUCE'] = native
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    ev = DistributedEvaluator(eng, device=torch.device('cuda', 0), force_collectives=True)
+    assert ev.native == (native == '1'), (native, ev.native)
+    if ev.native:
+        info = eng.comm_info(probe=True)                 # the library's own answer to "how many ranks did RCCL connect"
+        assert info['ranks'] == 1 and info['rank'] == 0 and info['probe_sum'] == 1.0 and info['stats_bytes'] == 8 * (M * (M + 1) // 2 + M * D + 8), info
+    out = ev.evaluate(False)
+    st, gt = ev._tensors()
+    assert st.is_cuda and st.dtype == torch.float64 and st.data_ptr() == eng.stats_packed_buffer()[0] and gt.data_ptr() == eng.grads_buffer()[0]
+    assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F'])
+    assert np.max(np.abs(out['grad_Z'] - ref['grad_Z'])) <= 1e-5 * np.max(np.abs(ref['grad_Z']))
+    eng.close()
+dist.destroy_process_group()
+print('RCCL_OK')
+"""
+
+
+def test_rccl_allreduce_on_the_packed_device_buffers():
+    """The N>1 path on one GPU, in a fresh process: a 1-rank RCCL group all-reduces the engine's packed device buffers
+    in place and the evaluation still matches the oracle -- through the library's own communicator (gp_comm_init / gp_allreduce) and
+    through torch.distributed on a zero-copy view of the library's memory (GPARML_NATIVE_ALLREDUCE=0), both in ONE process."""
+    r = subprocess.run([sys.executable, '-c', RCCL_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+NATIVE_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+N, D, M, Q = 700, 5, 33, 3
+d = Fz.synthetic_shard(N, D, M, Q, regime='B', seed=5, zseed=6, alpha_value=0.4)
+eng = ShardEngine(N, D, M, Q)
+eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+plain = eng.evaluate(True)
+try:
+    eng.allreduce('stats')
+    raise SystemExit('gp_allreduce without a communicator did not fail')
+except RuntimeError as e:
+    assert 'gp_comm_init' in str(e), e
+eng.comm_init(ShardEngine.comm_unique_id(), 1, 0)          # what a C consumer does: no torch in this process
+eng.phase1(); eng.allreduce('stats'); eng.global_step(sync=False); eng.phase2(True); eng.allreduce('grads')
+out = eng.finish()
+assert out['F'] == plain['F'] and np.array_equal(out['grad_Z'], plain['grad_Z']) and np.array_equal(out['grad_alpha'], plain['grad_alpha'])
+eng.comm_destroy(); eng.close()
+assert 'torch' not in sys.modules
+print('NATIVE_OK')
+"""
+
+
+def test_library_allreduce_without_torch():
+    """gp_comm_unique_id / gp_comm_init / gp_allreduce (RCCL resolved by dlopen inside the library) in a process that never imports torch: a
+    one-rank communicator leaves the evaluation bit-identical; gp_allreduce before gp_comm_init is a state error."""
+    r = subprocess.run([sys.executable, '-c', NATIVE_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'NATIVE_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 RANK_SCRIPT = r"""
 import os, sys
 sys.path.insert(0, %(root)r)

@@ -17,6 +17,7 @@ from multiprocessing.pool import ThreadPool
 import numpy as np
 import pytest
 
+import oracle_cache
 from conftest import ROOT, assert_close
 
 pytestmark = pytest.mark.gpu
@@ -206,19 +207,25 @@ def test_oracle_on_a_2e4_point_slice_of_the_same_workload(data):
     ncpu = os.cpu_count() or 8
     workers = min(32, ncpu)            # OpenBLAS is built for 64 caller threads: more concurrent callers corrupt its buffer table
     t = time.time()
-    with threadpool_limits(limits=max(1, ncpu // workers)):
-        ref = Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], Y, mu, S, shards=64, workers=workers, pairs='gemm')
+
+    def live():
+        with threadpool_limits(limits=max(1, ncpu // workers)):
+            return Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], Y, mu, S, shards=64, workers=workers, pairs='gemm')
+
+    # 95 s on 256 host threads when computed live: the oracle's outputs for this seeded slice are committed (tests/oracle_cache.py)
+    ref = oracle_cache.get('config4_fullsize_slice_2e4', dict(Y=Y, X_mu=mu, X_S=S, Z=d['Z'], alpha=d['alpha'], beta=d['beta'], sf2=d['sf2']), live)
     t_ref = time.time() - t
+    oracle_cache.done()
     eng = ShardEngine(n, D, M, Q)
     eng.upload_shard(Y, mu, S)
     eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
     out = eng.evaluate(True)
     ms = eng.timings()['total_ms']
     eng.close()
-    print('oracle on 2e4 points: %.1f s on %d host threads; device %.1f ms' % (t_ref, ncpu, ms))
+    print('oracle on 2e4 points: %.1f s (live on %d host threads, or read from tests/golden/oracle_cache); device %.1f ms' % (t_ref, ncpu, ms))
     errs = {k: float(np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k])))
-            for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S')}
+            for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S') if not hasattr(ref[k], 'rows')}
     _report(oracle_2e4={'oracle_s': round(t_ref, 1), 'host_threads': ncpu, 'device_ms': ms, 'F_rel': abs(out['F'] - ref['F']) / abs(ref['F']), 'errors': errs})
     assert_close(out['F'], ref['F'], 1e-6, what='F')
-    for k in errs:
+    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S'):
         assert_close(out[k], ref[k], 1e-5, what=k)

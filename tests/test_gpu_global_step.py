@@ -250,3 +250,41 @@ def test_fixed_embedding_preparation_cache_follows_the_hyper_parameters():
         for k in ('grad_Z', 'grad_alpha'):
             assert np.max(np.abs(out[k] - ref[k])) <= 1e-8 * np.max(np.abs(ref[k])), k
     eng.close()
+
+
+@pytest.mark.parametrize('N,D,M,Q,regime,emb', [(100000, 10, 128, 10, 'A', False), (100000, 10, 128, 10, 'A', True), (20000, 10, 128, 10, 'B', True),
+                                              (3000, 5, 70, 4, 'A', False), (900, 128, 33, 11, 'B', True), (2000, 1, 1, 1, 'A', False)])
+def test_fused_one_panel_tail_is_bit_identical_to_the_separate_launches(N, D, M, Q, regime, emb):
+    """M, D <= 128 (BASELINE configs[1] is M = 128, D = 10): everything of the global step behind the panel factorisation runs as ONE persistent
+    kernel (gs_tail128_kernel, csrc/linalg.hip: eight stages behind agent-scope barriers) instead of fifteen launches.  The stages call the same
+    device functions as the separate kernels, so the bound, every gradient, the partials (partial_terms.py:102-138) and the inverses
+    (partial_terms.py:60, 95) must agree BIT FOR BIT with the library run with the fused kernel switched off (gp_debug_set_option('gs_tail', 0)),
+    also without the two extended-precision pieces, and on a repeated evaluation."""
+    from gparml_amd import _lib
+    from gparml_amd.engine import ShardEngine
+    from oracle import factorised as Fz
+    lib = _lib.load()
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=60, zseed=61, alpha_value=min(0.5, 1.0 / Q) if M > 1 else 0.5)
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+
+    def run(tail, dd=1, refine=1):
+        assert lib.gp_debug_set_option(b'gs_tail', tail) == 0 and lib.gp_debug_set_option(b'dd_kipsi2', dd) == 0 and lib.gp_debug_set_option(b'refine_E', refine) == 0
+        eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        o = eng.evaluate(emb)
+        res = {k: np.array(o[k]) for k in ('F', 'grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta')}
+        for name in ('KMM_INV', 'KMM_PLUS_OP_INV', 'DF_DKMM', 'DF_DPSI1TY', 'DF_DPSI2'):
+            res[name] = eng.download(name)
+        if emb:
+            res['gmu'], res['gS'] = eng.download('GRAD_X_MU'), eng.download('GRAD_X_S')
+        return res
+
+    try:
+        for dd, refine in ((1, 1), (0, 0)):
+            a, b, again = run(1, dd, refine), run(0, dd, refine), run(1, dd, refine)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), ('fused vs separate', k, dd, refine, float(np.max(np.abs(a[k] - b[k]))))
+                assert np.array_equal(a[k], again[k]), ('fused, repeated', k)
+    finally:
+        lib.gp_debug_set_option(b'gs_tail', 1); lib.gp_debug_set_option(b'dd_kipsi2', 1); lib.gp_debug_set_option(b'refine_E', 1)
+        eng.close()

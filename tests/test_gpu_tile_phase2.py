@@ -12,6 +12,7 @@ import sys
 import numpy as np
 import pytest
 
+import oracle_cache
 from conftest import ROOT, assert_close
 
 pytestmark = pytest.mark.gpu
@@ -59,8 +60,9 @@ def test_config4_shape_with_more_points_than_inducing_points():
     rs = np.random.RandomState(7)
     d = Fz.synthetic_shard(N, D, 64, Q, regime='B', seed=6, zseed=7, alpha_value=1.0 / Q)
     d['Z'] = d['X_mu'][rs.permutation(N)[:M]] + 0.3 * rs.randn(M, Q)
-    ref = Fz.evaluate_sharded(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=32, workers=min(32, os.cpu_count() or 8),
-                              pairs='gemm')
+    ref = oracle_cache.get('config4_shape_N2048', d, lambda: Fz.evaluate_sharded(
+        d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], shards=32, workers=min(32, os.cpu_count() or 8), pairs='gemm'))
+    oracle_cache.done()
     eng = ShardEngine(N, D, M, Q)
     eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
     eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])

@@ -197,25 +197,37 @@ def config1_extra(device, steps=50):
     Zs = [d['Z'] + 1e-3 * rs.randn(M, Q) for _ in range(steps)]
     eng = ShardEngine(N, D, M, Q, device=device)
     eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    # wall clock: what an optimiser pays per evaluation -- no timing events on the stream (gp_set_timing(0): each of the thirteen events of an
+    # evaluation is a signal packet the stream idles on for 4-7 us, 15 % of an evaluation at this size)
+    eng.set_timing(0)
     for i in range(5):
         eng.set_globals(Zs[i], d['sf2'], d['alpha'], d['beta'])
         out = eng.evaluate(False)
-    dev = 0.0
     t0 = time.time()
     for i in range(steps):
         eng.set_globals(Zs[i], d['sf2'], d['alpha'], d['beta'])
         out = eng.evaluate(False)
     wall = (time.time() - t0) / steps * 1e3
-    for i in range(10):                      # device time of the kernels (gp_last_timings synchronises: read outside the wall-clock loop)
+    # device time of one evaluation from its first to its last kernel: two events only (level 1), read outside the wall-clock loop
+    eng.set_timing(1)
+    dev = 0.0
+    for i in range(10):
         eng.set_globals(Zs[i], d['sf2'], d['alpha'], d['beta'])
         out = eng.evaluate(False)
         dev += eng.timings()['total_ms'] / 10
-    tm = eng.timings()
+    # per-kernel events (level 2, the default): the breakdown; their own idle time is in these numbers
+    eng.set_timing(2)
+    tm = {}
+    for i in range(10):
+        eng.set_globals(Zs[i], d['sf2'], d['alpha'], d['beta'])
+        out = eng.evaluate(False)
+        for k, v in eng.timings().items():
+            tm[k] = tm.get(k, 0.0) + v / 10
     eng.close()
     W = float(N) * M * (3.0 * M + 4.0 * D + 12.0 * Q)
     return {'workload': 'BASELINE configs[1]: N=1e5, D=10, M=128, Q=10, fixed embeddings, new global parameters every step', 'N': N, 'D': D, 'M': M, 'Q': Q,
             'ms_per_eval_wall': wall, 'evals_per_s': 1e3 / wall, 'device_ms': dev, 'host_enqueue_share': max(0.0, 1.0 - dev / wall),
-            'global_ms': tm['global_ms'], 'eval_flops_survey_8d': W, 'frac': W / (wall * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 'F': out['F']}
+            'global_ms': tm['global_ms'], 'device_ms_by_stage_with_per_kernel_events': {k: round(v, 4) for k, v in tm.items()}, 'eval_flops_survey_8d': W, 'frac': W / (wall * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 'F': out['F']}
 
 
 def cpu_baseline(D, M, Q, N_full, budget_rows):

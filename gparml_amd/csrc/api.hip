@@ -200,6 +200,13 @@ extern "C" int gp_memory_info(gp_ctx* c, int64_t* free_bytes, int64_t* total_byt
   return GP_OK;
 }
 
+extern "C" int gp_set_timing(gp_ctx* c, int level) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (level < 0 || level > 2) return fail(c, GP_ERR_BAD_ARG, "gp_set_timing: level must be 0 (no events), 1 (total only) or 2 (every phase and kernel)");
+  c->timing = level;
+  return GP_OK;
+}
+
 extern "C" int gp_set_stream(gp_ctx* c, void* s) {
   if (!c) return GP_ERR_BAD_ARG;
   c->stream = (hipStream_t)s;
@@ -304,9 +311,12 @@ extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const doub
   const int slot = c->glob_slot;
   if (!c->h_glob[slot]) {
     GP_HIP(c, hipHostMalloc((void**)&c->h_glob[slot], (nz + nq) * sizeof(double), hipHostMallocMapped));
-    GP_HIP(c, hipEventCreateWithFlags(&c->glob_ev[slot], hipEventDisableTiming));
-  } else {
-    GP_HIP(c, hipEventSynchronize(c->glob_ev[slot]));   // the copy issued from this slot two calls ago (long complete in any real sequence)
+  } else if (c->glob_epoch[slot] >= c->sync_epoch) {
+    // the kernel that read this slot two calls ago may still be queued: no stream synchronisation has been seen since (never the case in an
+    // optimiser's sequence -- every evaluation ends in gp_finish's synchronisation -- so no event is recorded per call: that was one more signal
+    // packet on the stream)
+    GP_HIP(c, hipStreamSynchronize(c->stream));
+    ++c->sync_epoch;
   }
   std::memcpy(c->h_glob[slot], Z, nz * sizeof(double));
   std::memcpy(c->h_glob[slot] + nz, alpha, nq * sizeof(double));
@@ -315,7 +325,7 @@ extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const doub
   hipLaunchKernelGGL(zaug_kernel, dim3((std::max(c->Mp, c->Q) + 255) / 256), dim3(256), 0, c->stream, dslot, dslot + nz, c->M, c->Mp, c->Q, c->CZp, c->Z,
                      c->Zaug, c->alpha);
   GP_HIP(c, hipGetLastError());
-  GP_HIP(c, hipEventRecord(c->glob_ev[slot], c->stream));   // the slot may be rewritten once this kernel has read it
+  c->glob_epoch[slot] = c->sync_epoch;                      // the slot may be rewritten once a later stream synchronisation has passed
   c->glob_slot = slot ^ 1;
   c->sf2 = sf2; c->beta = beta; c->N_global = N_global; c->step = step;
   c->have_globals = true;
@@ -327,13 +337,13 @@ extern "C" int gp_phase1(gp_ctx* c) {
   if (!c) return GP_ERR_BAD_ARG;
   if (!c->have_data || !c->have_globals) return fail(c, GP_ERR_STATE, "gp_phase1 needs gp_upload_shard and gp_set_globals first");
   GP_HIP(c, hipSetDevice(c->device));
-  GP_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  GP_EV(c, 0);
   GP_TRY(run_prep_and_generate(c));
   if (!c->regime_A) GP_TRY(run_generate_b(c));
-  GP_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  GP_EV(c, 1);
   GP_TRY(run_phase1(c));
   if (!c->regime_A) GP_TRY(run_phase1_b(c));
-  GP_HIP(c, hipEventRecord(c->ev[2], c->stream));
+  GP_EV(c, 2);
   c->state = 1;
   c->spack_filled = false;
   return GP_OK;
@@ -498,9 +508,9 @@ extern "C" int gp_global_step_jitter(gp_ctx* c, int jitter_mask) {
   if (jitter_mask < 0 || jitter_mask > 3) return fail(c, GP_ERR_BAD_ARG, "gp_global_step_jitter: mask must be 0..3");
   GP_HIP(c, hipSetDevice(c->device));
   c->jitter_mask = jitter_mask;
-  GP_HIP(c, hipEventRecord(c->ev[3], c->stream));
+  GP_EV(c, 3);
   const int rc_gs = run_global_step(c);
-  GP_HIP(c, hipEventRecord(c->ev[4], c->stream));
+  GP_EV(c, 4);
   if (rc_gs != GP_OK) return rc_gs;
   c->state = 2;
   return GP_OK;
@@ -522,7 +532,7 @@ extern "C" int gp_phase2(gp_ctx* c, int want_embedding_grads) {
   if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_phase2 before gp_global_step");
   if (!c->have_data) return fail(c, GP_ERR_STATE, "gp_phase2 without shard data");
   GP_HIP(c, hipSetDevice(c->device));
-  GP_HIP(c, hipEventRecord(c->ev[5], c->stream));
+  GP_EV(c, 5);
   if ((want_embedding_grads != 0) != c->want_emb) {
     // the per-point feature matrix depends on the mode: rebuild the trial point
     c->want_emb = want_embedding_grads != 0;
@@ -538,7 +548,7 @@ extern "C" int gp_phase2(gp_ctx* c, int want_embedding_grads) {
     GP_HIP(c, hipGetLastError());
     c->have_glatest = true;
   }
-  GP_HIP(c, hipEventRecord(c->ev[6], c->stream));
+  GP_EV(c, 6);
   c->state = 3;
   return GP_OK;
 }
@@ -550,6 +560,12 @@ extern "C" int gp_last_timings(gp_ctx* c, double* out8) {
   GP_HIP(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < 8; ++i) out8[i] = 0.0;
   float ms;
+  ++c->sync_epoch;
+  if (c->timing == 1) {       // only the evaluation's first and last event were recorded
+    if (c->state >= 3 && hipEventElapsedTime(&ms, c->ev[0], c->ev[6]) == hipSuccess) out5[4] = ms;
+    return GP_OK;
+  }
+  if (c->timing == 0) return GP_OK;
   if (c->state >= 1 && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) out5[0] = ms;
   if (c->state >= 1 && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) out5[1] = ms;
   if (c->state >= 2 && hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) out5[2] = ms;
@@ -677,6 +693,7 @@ extern "C" int gp_finish(gp_ctx* c, double* F, double* grad_Z, double* grad_sf2,
     hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(ngs + n)), dim3(256), 0, c->stream, c->gs, ngs, c->gK, c->grads, n, dout);
     GP_HIP(c, hipGetLastError());
     GP_HIP(c, hipStreamSynchronize(c->stream));
+    ++c->sync_epoch;
     GP_TRY(check_global_from(c, c->gs_pending ? c->h_out : nullptr));
     if (grad_Z) memcpy(grad_Z, c->h_out + ngs, (size_t)c->M * c->Q * 8);
     if (grad_alpha) memcpy(grad_alpha, c->h_out + ngs + (size_t)c->M * c->Q, (size_t)c->Q * 8);

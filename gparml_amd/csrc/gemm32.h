@@ -65,7 +65,10 @@ __device__ __forceinline__ void gemm32_tile(const GemmP& p, int bx, int by, int 
   const long a_step = (LA == K_CONTIG) ? SKC : (long)SKC * p.lda;
   const long b_step = (LB == K_CONTIG) ? SKC : (long)SKC * p.ldb;
   const int nc = (p.K + SKC - 1) / SKC;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  // NOT zeroed in C++: hipcc rematerialises such zeros as v_mov_b64 right in front of the first asm MFMA of each accumulator, and in the fused
+  // tail kernel it put one of them on a register the previous MFMA was still reading as its B operand (columns 4..7 of every tile wrong, r05).
+  // The first k-step of the first chunk takes C = 0 as an inline constant instead (mfma444_zero).
+  double acc[4];
   const unsigned aA = lds_byte_addr(sA) + 8u * (unsigned)(LA == K_CONTIG ? (wr + lr) * LDA + lk : lk * LDA + wr + lr);
   const unsigned aB = lds_byte_addr(sB) + 8u * (unsigned)(LB == K_CONTIG ? (wc + lj) * LDB + lk : lk * LDB + wc + lj);
   double2 ra[8], rb[8];
@@ -93,8 +96,13 @@ __device__ __forceinline__ void gemm32_tile(const GemmP& p, int bx, int by, int 
       constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
       if constexpr (k4 + 1 < SKC / 4) { rd(IC<k4 + 1>{}, a[cur ^ 1], b[cur ^ 1]); lgkm_wait<5>(); }
       else lgkm_wait<0>();
+      if (k4 == 0 && c == 0) {
 #pragma unroll
-      for (int bc = 0; bc < 4; ++bc) mfma444_acc(acc[bc], a[cur], b[cur][bc]);
+        for (int bc = 0; bc < 4; ++bc) mfma444_zero(acc[bc], a[cur], b[cur][bc]);
+      } else {
+#pragma unroll
+        for (int bc = 0; bc < 4; ++bc) mfma444_acc(acc[bc], a[cur], b[cur][bc]);
+      }
     });
     __syncthreads();
   }

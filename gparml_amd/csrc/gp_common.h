@@ -184,7 +184,12 @@ struct gp_ctx {
   hipEvent_t glob_ev[2] = {nullptr, nullptr};
   int glob_slot = 0;
   double* h_out = nullptr;    // gp_finish: pinned, mapped [GS_COUNT + 8 | M*Q + Q] -- finish_kernel writes the evaluation's results straight into it
-  // timing
+  // timing: 2 = HIP events around every phase and the dominant kernels (gp_last_timings reports all eight numbers; the default), 1 = only the
+  // evaluation's first and last event (total_ms), 0 = none.  Every recorded event is a signal packet the stream waits on: ~4-7 us of idle
+  // stream each, thirteen per evaluation -- 0.3 % of an evaluation at configs[2]'s size, 15 % at configs[1]'s (gp_set_timing)
+  int timing = 2;
+  long sync_epoch = 0;        // stream synchronisations seen so far (gp_set_globals' pinned slots are reused without an event once one has passed)
+  long glob_epoch[2] = {-1, -1};
   hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double t_ms[5] = {0, 0, 0, 0, 0};
 };
@@ -234,6 +239,8 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
                           double* splitk_ws /*may be NULL*/);
 }  // namespace gp
 
+// event i of the context's timing set, if the timing level asks for it (levels: gp_ctx::timing)
+#define GP_EV(c, i) do { if ((c)->timing >= 2 || ((c)->timing == 1 && ((i) == 0 || (i) == 6))) (void)hipEventRecord((c)->ev[i], (c)->stream); } while (0)
 #define GP_TRY_RC(x) do { int rc__ = (x); if (rc__ != GP_OK) return rc__; } while (0)
 #define GP_HIP(ctx, call)                                                                         \
   do {                                                                                            \

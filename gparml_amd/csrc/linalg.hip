@@ -413,7 +413,7 @@ struct TailP {
   double* gs; double* gK; unsigned* bar;
   DotJobs jobs;
   double beta, sf2, Dd, Nglob, jitA;
-  int M, Q, regimeA, refine, dd;
+  int M, Q, regimeA, refine, dd, stop;
 };
 __device__ __forceinline__ void tail_barrier(unsigned* bar, unsigned target) {
   __syncthreads();
@@ -446,6 +446,7 @@ __global__ void __launch_bounds__(256, 1) gs_tail128_kernel(TailP p) {
     for (int t = wg; t < 32; t += TAIL_WGS) gemm32_tile<FREE_CONTIG, FREE_CONTIG>(r, t & 3, (t >> 2) & 3, t >> 4, sA, sB);
   }
   tail_barrier(p.bar, TAIL_WGS * ++stage);
+  if (p.stop == (int)stage) return;
   // S2: E = P C (16 tiles)  |  T2 = Ki Psi2, accumulated in double-double (32 blocks) or on the matrix core (16 tiles)
   {
     GemmP e = g;
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(256, 1) gs_tail128_kernel(TailP p) {
     }
   }
   tail_barrier(p.bar, TAIL_WGS * ++stage);
+  if (p.stop == (int)stage) return;
   // S3: dFdK(tmp) = T2 Ki (16 tiles)  |  R = C - A E in double-double, one row per item, into PsiE (rows >= M: zero)
   {
     GemmP k = g;
@@ -477,12 +479,14 @@ __global__ void __launch_bounds__(256, 1) gs_tail128_kernel(TailP p) {
     }
   }
   tail_barrier(p.bar, TAIL_WGS * ++stage);
+  if (p.stop == (int)stage) return;
   // S4: E += P R
   if (p.refine) {
     GemmP e = g;
     e.K = Mp; e.A = P; e.lda = Mp; e.B = p.PsiE; e.ldb = Dp; e.C = p.E; e.ldc = Dp; e.beta = 1.0;
     for (int t = wg; t < 16; t += TAIL_WGS) gemm32_tile<K_CONTIG, FREE_CONTIG>(e, t & 3, t >> 2, 0, sA, sB);
     tail_barrier(p.bar, TAIL_WGS * ++stage);
+  if (p.stop == (int)stage) return;
   }
   // S5: PsiE = Psi2 E (16 tiles)  |  T1 = E E^T (16 tiles)
   {
@@ -496,10 +500,12 @@ __global__ void __launch_bounds__(256, 1) gs_tail128_kernel(TailP p) {
     }
   }
   tail_barrier(p.bar, TAIL_WGS * ++stage);
+  if (p.stop == (int)stage) return;
   // S6: the assembled partials and the phase-2 operand
   for (long idx = wg * 256L + threadIdx.x; idx < mm + (long)Mp * Dp; idx += TAIL_WGS * 256L)
     assemble_elem(idx, Ki, P, p.T1, p.dFdK, p.E, p.beta, p.Dd, Mp, Dp, p.Bbar, p.dFdK, p.Abar, p.Bm);
   tail_barrier(p.bar, TAIL_WGS * ++stage);
+  if (p.stop == (int)stage) return;
   // S7: the seven traces (jobs x 64 blocks)  |  K_mm parts of grad_Z / grad_alpha, two rows per pass (alpha partials per row through T2)
   {
     double* dpart = p.gs + GS_COUNT + 8;
@@ -514,6 +520,7 @@ __global__ void __launch_bounds__(256, 1) gs_tail128_kernel(TailP p) {
     }
   }
   tail_barrier(p.bar, TAIL_WGS * ++stage);
+  if (p.stop == (int)stage) return;
   // S8: F, grad_beta, grad_sf2  |  column sums of the alpha partials
   if (wg == 0) scalars_block(p.sc, p.gs, p.jobs, p.gs + GS_COUNT + 8, p.beta, p.sf2, p.Dd, p.Nglob);
   else for (int q = wg - 1; q < p.Q; q += TAIL_WGS - 1) colsum_block(p.T2, p.M, p.Q, p.gK + (long)p.M * p.Q, q, red);
@@ -527,6 +534,7 @@ int check_global(gp_ctx* c) {
     double h[GS_COUNT + 8];
     GP_HIP(c, hipMemcpyAsync(h, c->gs, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     GP_HIP(c, hipStreamSynchronize(c->stream));
+    ++c->sync_epoch;
     return check_global_from(c, h);
   }
   return check_global_from(c, nullptr);
@@ -585,6 +593,7 @@ int run_global_step(gp_ctx* c) {
     t.bar = reinterpret_cast<unsigned*>(c->gs + GS_COUNT + 4);     // a spare failure-flag slot: zeroed by build_kmm_kernel above
     t.beta = c->beta; t.sf2 = c->sf2; t.Dd = (double)D; t.Nglob = (double)c->N_global; t.jitA = (c->jitter_mask & 2) ? 1e-7 : 0.0;
     t.M = M; t.Q = Q; t.regimeA = c->regime_A ? 1 : 0; t.refine = g_opt_refine_E.load(); t.dd = g_opt_dd_kipsi2.load();
+    { const char* e = getenv("GPARML_TAIL_STOP"); t.stop = e ? atoi(e) : 0; }
     t.jobs.n = 7;
     t.jobs.j[0] = {c->Inv, Psi2, Mp, M, M, GS_TR_KIPSI2};
     t.jobs.j[1] = {c->Inv + mm, Psi2, Mp, M, M, GS_TR_PPSI2};
@@ -724,4 +733,30 @@ extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double
   }
   (void)hipFree(dA); (void)hipFree(dLi); (void)hipFree(dInv); (void)hipFree(dT); (void)hipFree(dS);
   return rc;
+}
+
+// raw copy of an internal buffer of the global step (developer tool, tests/devtools/dev_tail_diff.py; not part of the public header)
+extern "C" int gp_debug_peek(gp_ctx* c, const char* name, double* out, long n) {
+  using namespace gp;
+  if (!c || !name || !out) return GP_ERR_BAD_ARG;
+  GP_HIP(c, hipSetDevice(c->device));
+  const long mm = (long)c->Mp * c->Mp, md = (long)c->Mp * c->Dp;
+  const double* src = nullptr; long cnt = 0;
+  if (!std::strcmp(name, "Linv")) { src = c->Linv; cnt = 2 * mm; }
+  else if (!std::strcmp(name, "Inv")) { src = c->Inv; cnt = 2 * mm; }
+  else if (!std::strcmp(name, "E")) { src = c->E; cnt = md; }
+  else if (!std::strcmp(name, "PsiE")) { src = c->PsiE; cnt = md; }
+  else if (!std::strcmp(name, "T1")) { src = c->T1; cnt = mm; }
+  else if (!std::strcmp(name, "T2")) { src = c->T2; cnt = mm; }
+  else if (!std::strcmp(name, "dFdK")) { src = c->dFdK; cnt = mm; }
+  else if (!std::strcmp(name, "Bbar")) { src = c->Bbar; cnt = mm; }
+  else if (!std::strcmp(name, "Abar")) { src = c->Abar; cnt = md; }
+  else if (!std::strcmp(name, "Bm")) { src = c->Bm; cnt = (long)c->LDK * c->Mp; }
+  else if (!std::strcmp(name, "gK")) { src = c->gK; cnt = (long)c->M * c->Q + c->Q; }
+  else if (!std::strcmp(name, "gs")) { src = c->gs; cnt = GS_COUNT + 8 + 8 * 64; }
+  else return fail(c, GP_ERR_BAD_ARG, "gp_debug_peek: unknown buffer '%s'", name);
+  if (n < cnt) return fail(c, GP_ERR_BAD_ARG, "gp_debug_peek: %ld doubles needed", cnt);
+  GP_HIP(c, hipStreamSynchronize(c->stream));
+  GP_HIP(c, hipMemcpy(out, src, cnt * 8, hipMemcpyDeviceToHost));
+  return (int)GP_OK;
 }

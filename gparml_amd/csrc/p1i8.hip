@@ -361,9 +361,9 @@ int run_phase1_i8(gp_ctx* c) {
   a.Sl = pl->Sl; a.strideJ = pl->strideJ; a.LDK = c->LDK; a.jobs = pl->jobs; a.part = c->part;
   constexpr int lds = I8_STAGES * I8_STAGE;
   GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(p1i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  (void)hipEventRecord(c->ev[10], c->stream);
+  GP_EV(c, 10);
   hipLaunchKernelGGL(p1i8_kernel, dim3(pl->blocks), dim3(512), lds, c->stream, a);
-  (void)hipEventRecord(c->ev[11], c->stream);
+  GP_EV(c, 11);
   GP_HIP(c, hipGetLastError());
   double* Psi2 = c->stats;
   double* C = c->stats + (long)c->Mp * c->Mp;

@@ -331,10 +331,10 @@ int run_phase1_v2(gp_ctx* c) {
   }
   P1v2Args p;
   p.Kaug = c->Kaug; p.ld = c->LDK; p.jobs = pl->jobs; p.part = c->part;
-  (void)hipEventRecord(c->ev[10], c->stream);
+  GP_EV(c, 10);
   if (pl->nby == 8) hipLaunchKernelGGL((p1v2_kernel<8>), dim3(pl->blocks), dim3(512), 0, c->stream, p);
   else hipLaunchKernelGGL((p1v2_kernel<26>), dim3(pl->blocks), dim3(512), 0, c->stream, p);
-  (void)hipEventRecord(c->ev[11], c->stream);
+  GP_EV(c, 11);
   GP_HIP(c, hipGetLastError());
   double* Psi2 = c->stats;
   double* C = c->stats + (long)c->Mp * c->Mp;

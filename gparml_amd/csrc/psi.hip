@@ -520,7 +520,7 @@ int run_prep_and_generate(gp_ctx* c) {
   }
   c->prep_fixa_valid = fixa;
   c->i8_active = fixa && p1i8_applicable(c);     // decided per evaluation (gp_debug_set_option("p1_i8", ...) switches it at run time)
-  (void)hipEventRecord(c->ev[8], c->stream);
+  GP_EV(c, 8);
   const int QP = psi1_qp(c->Q);
   // The Psi1 kernels' fixed-variance form (u = alpha, ln c1 = ln sf2: 2 Q + 14 issue slots per element instead of 3 Q + 14) only needs every variance
   // to be zero -- not the fixed-embedding FEATURE layout, which the fast kernel uses for Q + 1 <= 12 -- so it also serves regime A with embedding gradients and
@@ -549,7 +549,7 @@ int run_prep_and_generate(gp_ctx* c) {
     hipLaunchKernelGGL(psi1_generic_kernel, grid, dim3(256), 0, c->stream, c->mu, c->U, c->lnc1, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M,
                        c->Q, (long)c->LDK);
   }
-  (void)hipEventRecord(c->ev[9], c->stream);
+  GP_EV(c, 9);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
 }
@@ -614,9 +614,9 @@ int run_phase1(gp_ctx* c) {
   }
   p.bmap = c->bmap;
   const int blocks = c->bmap_blocks;
-  (void)hipEventRecord(c->ev[10], c->stream);
+  GP_EV(c, 10);
   hipLaunchKernelGGL(p1_kernel8, dim3(blocks), dim3(512), 0, c->stream, p);
-  (void)hipEventRecord(c->ev[11], c->stream);
+  GP_EV(c, 11);
   GP_HIP(c, hipGetLastError());
   double* Psi2 = c->stats;
   double* C = c->stats + (long)c->Mp * c->Mp;
@@ -1295,7 +1295,7 @@ int run_phase2(gp_ctx* c) {
   p.klast = ((c->D - 1) % KC) / 4 + 1;
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
   const int nrb = (c->Q + 1 + 3) / 4;                // fast path: feature columns [mu (Q) | 1] in groups of four
-  (void)hipEventRecord(c->ev[12], c->stream);
+  GP_EV(c, 12);
   p.dbg = nullptr;
 #ifdef GPARML_GEN8_TIMING
   static long long* g8dbg = nullptr;
@@ -1325,7 +1325,7 @@ int run_phase2(gp_ctx* c) {
       default: hipLaunchKernelGGL((p2_fast8_kernel<3>), dim3(blocks), dim3(512), 0, c->stream, p); break;
     }
   }
-  (void)hipEventRecord(c->ev[13], c->stream);
+  GP_EV(c, 13);
   GP_HIP(c, hipGetLastError());
   double* gZ = c->grads;
   double* ga = c->grads + (long)c->M * c->Q;

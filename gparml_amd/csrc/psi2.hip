@@ -936,7 +936,7 @@ static void launch_pairs_mfma(gp_ctx* c, int S) {
 
 int run_phase1_b(gp_ctx* c) {
   // gp_last_timings' "p1 kernel" slot: in regime B the Psi2 pair kernel (the C tiles' p1_kernel8 launch recorded the events before)
-  (void)hipEventRecord(c->ev[10], c->stream);
+  GP_EV(c, 10);
   // the matrix-core pair kernel from the 24-wide latent tables on (17 <= Q): same-box, N = 1e5, M = 512, ms of this kernel at Q = 17 / 20 / 24:
   // 21.4 / 21.4 / 21.8 against 30.5 for psi2_pairs_kernel<24>; at 16 columns the VALU kernel is still ahead (15.3 ms measured against ~17 by the instruction count)
   if (c->b_mfma || c->QB == 24) {
@@ -949,7 +949,7 @@ int run_phase1_b(gp_ctx* c) {
       case 52: launch_pairs_mfma<52>(c, S); break;
       default: launch_pairs_mfma<64>(c, S); break;
     }
-    (void)hipEventRecord(c->ev[11], c->stream);
+    GP_EV(c, 11);
     GP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(psi2_reduce64_kernel, dim3(c->n_tiles64), dim3(256), 0, c->stream, c->part, c->tiles64, c->n_tiles64, S, c->M, c->Mp, c->stats);
     GP_HIP(c, hipGetLastError());
@@ -972,7 +972,7 @@ int run_phase1_b(gp_ctx* c) {
     case 52: launch_pairs<52>(c, S); break;
     default: launch_pairs<64>(c, S); break;
   }
-  (void)hipEventRecord(c->ev[11], c->stream);
+  GP_EV(c, 11);
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_reduce_kernel, dim3(c->n_ptiles), dim3(256), 0, c->stream, c->part, c->ptiles, c->n_ptiles, S, c->M, c->Mp, c->stats);
   GP_HIP(c, hipGetLastError());
@@ -1018,7 +1018,7 @@ int run_phase2_b(gp_ctx* c) {
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
   a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb; a.ngrp = (c->nslab + std::min(4, c->nslab) - 1) / std::min(4, c->nslab);
-  (void)hipEventRecord(c->ev[12], c->stream);   // gp_last_timings' "p2 kernel" slot: in regime B the T_n = Bbar o psi2_n kernel
+  GP_EV(c, 12);   // gp_last_timings' "p2 kernel" slot: in regime B the T_n = Bbar o psi2_n kernel
   if (c->b_mfma) {
     a.ngrp = c->nslab;
     int rc = GP_OK;
@@ -1046,7 +1046,7 @@ int run_phase2_b(gp_ctx* c) {
     case 52: launch_cols<52, false>(c, a); break;
     default: launch_cols<64, false>(c, a); break;
   }
-  (void)hipEventRecord(c->ev[13], c->stream);
+  GP_EV(c, 13);
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_points_finish_kernel, dim3((unsigned)std::min<long>(c->pb_blocks, 256)), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());

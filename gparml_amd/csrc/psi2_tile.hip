@@ -527,7 +527,7 @@ int run_phase2_b_tiles(gp_ctx* c) {
   PT2Fin f;
   f.pp = c->ppt; f.Wn = c->Wn; f.mu = c->mu; f.S = c->S; f.alpha = c->alpha; f.gmu = c->gXmu; f.gS = c->gXs; f.gapart2 = c->gapart2; f.CH = c->b_ch; f.Q = Q;
   const int fin_blocks = (int)std::min<long>(c->pb_blocks, 256);
-  (void)hipEventRecord(c->ev[12], c->stream);
+  GP_EV(c, 12);
   int k = 0;
   for (long n0 = 0; n0 < N; n0 += c->b_ch, ++k) {
     a.n0 = n0; a.n1 = std::min(N, n0 + c->b_ch); a.accumulate = k > 0 ? 1 : 0;
@@ -552,7 +552,7 @@ int run_phase2_b_tiles(gp_ctx* c) {
     hipLaunchKernelGGL(pt2_points_finish_kernel, dim3(fin_blocks), dim3(256), 0, c->stream, f);
     GP_HIP(c, hipGetLastError());
   }
-  (void)hipEventRecord(c->ev[13], c->stream);
+  GP_EV(c, 13);
 #ifdef GPARML_TILE_TIMING
   {
     std::vector<long long> h(ndbg);

@@ -256,6 +256,11 @@ class ShardEngine(object):
         self._ck(self.lib.gp_set_local_statistics(self.h, float(sum_YYT), p2, pc, float(sum_exp_K_ii), float(KL)),
                  'gp_set_local_statistics')
 
+    def set_timing(self, level):
+        """HIP timing events per evaluation: 2 = every stage and dominant kernel (default), 1 = first and last only (total_ms), 0 = none.
+        Each event is ~4-7 us of idle stream; an optimiser on a small problem (BASELINE configs[1]) switches them off."""
+        self._ck(self.lib.gp_set_timing(self.h, int(level)), 'gp_set_timing')
+
     def timings(self):
         t = np.zeros(8)
         self._ck(self.lib.gp_last_timings(self.h, t.ctypes.data_as(_lib._dp)), 'gp_last_timings')

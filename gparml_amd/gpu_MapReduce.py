@@ -235,6 +235,7 @@ def _prepare_shard(options, input_file_name, global_statistics):
                 sh['engine'].close()
             Y = _read_csv(input_file_name)
             eng = ShardEngine(Y.shape[0], options['D'], options['M'], options['Q'], device=_device_of(options, input_file_name))
+            eng.set_timing(0)          # nobody reads per-kernel device timings here (time_acc is host time): no timing events on the stream
             eng.upload_shard(Y, X_mu, X_S, xs_is_raw=not options['fixed_embeddings'])
             sh = _shards[key] = dict(engine=eng, shape=(Y.shape[0], options['D'], options['M'], options['Q']))
         else:

@@ -78,6 +78,7 @@ class partial_terms(object):
             if self._eng is not None:
                 self._eng.close()
             self._eng = ShardEngine(1 if N_s is None else N_s, self.D, self.M, self.Q, device=self.device)
+            self._eng.set_timing(0)
             self._have_data = False
             self._stats_on_device = False
             self._gstep_key = None

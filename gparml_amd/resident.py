@@ -20,6 +20,7 @@ class ResidentModel(object):
         self.engines = []
         for (Y, X_mu, X_S) in shards:
             e = ShardEngine(Y.shape[0], D, M, Q, device=device)
+            e.set_timing(0)            # an optimiser does not read per-kernel device timings: no timing events on the stream
             e.upload_shard(Y, X_mu, X_S, xs_is_raw=not fixed_embeddings)
             self.engines.append(e)
         self.group = dist_group

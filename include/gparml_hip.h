@@ -170,6 +170,11 @@ int gp_set_local_statistics(gp_ctx* ctx, double sum_YYT, const double* Psi2, con
  * out[0]=prep+Psi1 generation, [1]=phase-1 contraction+reduce, [2]=global step, [3]=phase 2, [4]=sum of [0..3],
  * out[5]=psi1_kernel alone, [6]=p1_kernel alone, [7]=p2_kernel alone */
 int gp_last_timings(gp_ctx* ctx, double* out8);
+/* How many timing events an evaluation records: 2 (default) = around every stage and the dominant kernels (all of gp_last_timings), 1 = only the
+ * first and the last one (gp_last_timings fills out[4], the whole evaluation, alone), 0 = none.  Every event is a signal packet the stream waits
+ * on (~4-7 us of idle stream each, thirteen per evaluation): nothing at configs[2]'s size, 15 % of an evaluation at configs[1]'s.  An optimiser
+ * that does not read the timings switches them off. */
+int gp_set_timing(gp_ctx* ctx, int level);
 /* hipMemGetInfo of ctx's device: bytes free / total right now (the footprint of a shard at BASELINE configs[4]'s per-GPU size is
  * OBSERVED with this; the reference has no counterpart -- its shard lives in the mapper process' numpy arrays,
  * local_MapReduce.py:197-201) */

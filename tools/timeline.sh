@@ -15,11 +15,11 @@ import csv, glob, json
 for f in glob.glob('$O/t/*kernel_trace.csv'):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    # one evaluation = from the Zaug build of gp_set_globals (zaug_kernel) to the gradient read-back of gp_finish (add_kernel + its copy):
+    # one evaluation = from the Zaug build of gp_set_globals (zaug_kernel) to the gradient read-back of gp_finish (finish_kernel + its copy):
     # take the last complete one
     st = [int(r['Start_Timestamp']) for r in rows]; en = [int(r['End_Timestamp']) for r in rows]
     starts = [i for i, r in enumerate(rows) if 'zaug_kernel' in r['Kernel_Name']]
-    ends = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('gp::add_kernel') or r['Kernel_Name'].startswith('add_kernel')]
+    ends = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('finish_kernel') or r['Kernel_Name'].startswith('finish_kernel')]
     b = ends[-1] + 1
     a = max(i for i in starts if i < b)
     t0 = st[a]

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstdarg>
 #include <string>
@@ -187,7 +188,7 @@ struct gp_ctx {
   // timing: 2 = HIP events around every phase and the dominant kernels (gp_last_timings reports all eight numbers; the default), 1 = only the
   // evaluation's first and last event (total_ms), 0 = none.  Every recorded event is a signal packet the stream waits on: ~4-7 us of idle
   // stream each, thirteen per evaluation -- 0.3 % of an evaluation at configs[2]'s size, 15 % at configs[1]'s (gp_set_timing)
-  int timing = 2;
+  int timing = [] { const char* e = getenv("GPARML_TIMING"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
   long sync_epoch = 0;        // stream synchronisations seen so far (gp_set_globals' pinned slots are reused without an event once one has passed)
   long glob_epoch[2] = {-1, -1};
   hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -392,138 +392,111 @@ __global__ void __launch_bounds__(256) colsum_kernel(const double* __restrict__ 
   colsum_block(part, rows, Q, out, blockIdx.x, red);
 }
 
-// ---------------------------------------------------------------------------------------------- fused tail for one-panel problems
+// ---------------------------------------------------------------------------------------------- short tail for one-panel problems
 // M <= 128 and D <= 128 (BASELINE configs[1]: M = 128, D = 10): everything of the global step behind the panel factorisation -- the two inverses,
 // E with its refinement step, Psi2 E, E E^T, K_mm^-1 Psi2 in double-double, its product with K_mm^-1, the assembled partials, the seven traces, the
 // scalars and the K_mm parts of the gradients -- used to be FIFTEEN launches of 4-12 us each, every one of them at the launch floor
-// (profiles/r05_config1_timeline.txt: 80 us for 2e7 flop).  Here they are the eight stages of ONE persistent kernel: 64 workgroups walk each stage's
-// work items (the same 32 x 32 tile products, double-double blocks, dot-product blocks and rows as the separate kernels: the device functions above
-// are shared, so the results are bit-identical), with an agent-scope barrier between stages.
-//   barrier: one counter (zeroed by build_kmm_kernel with the other scalars of the step); a workgroup's thread 0 releases (L2 write-back: the
-//   workgroups sit on eight XCDs with separate L2s), adds 1, spins until the count reaches 64 x stage, acquires (L1 / L2 invalidate); the scalar
-//   cache is invalidated by every wave (ddacc_block and residual_chain read rows that earlier stages wrote through scalar loads).
-// All 64 workgroups are resident at once (one per CU, 98 KB of LDS), which the spin needs; the stream's previous kernel has finished by then.
-constexpr int TAIL_WGS = 64;
+// (profiles/r05_config1_timeline.txt: 80 us for 2e7 flop).  Products that do not depend on each other now share a launch: SEVEN launches of one
+// kernel (tail_stage_kernel, stage = 0..6), every workgroup taking one work item of its stage -- the same 32 x 32 tile products, double-double
+// blocks, dot-product blocks and rows as the separate kernels (the device functions above are shared, so the results are bit-identical).
+//   0: [Ki ; P] = X^T X (32 tiles)                         1: E = P C (16 tiles) | T2 = Ki Psi2 in double-double (64 blocks)
+//   2: R = C - A E in double-double (128 rows) | T2 Ki (16 tiles)                    3: E += P R (16 tiles)
+//   4: Psi2 E (16 tiles, then Abar and Bm's lower block for the tile) | E E^T (16 tiles, then Bbar, dF/dKmm, Bm's upper block for the tile)
+//   5: the seven traces (7 x 64 blocks) | K_mm parts of grad_Z / grad_alpha (two rows per workgroup)        6: scalars | column sums
+// Why launches and not one persistent kernel with grid barriers: that was built first (r05) and measured at 94 us against 80 for the fifteen
+// launches -- on this part an agent-scope release + acquire (L2 write-back, L1 / L2 invalidate on eight XCDs) costs as much as a kernel boundary,
+// which does the same thing in hardware (MI355X_MICROARCH.md, inter-workgroup visibility: 1.7 + 1.7 us of fences + the counter round trips).
+constexpr int TAIL_STAGES = 7;
 constexpr int TAIL_LDS_DOUBLES = 2 * SmallImg<FREE_CONTIG>::DOUBLES;     // the larger operand image, twice (12288 doubles = 96 KB)
 struct TailP {
   const double* Linv; double* Inv;                    // [2][128][128]
   const double* Psi2; const double* C; const double* sc; const double* Keep;
   double *E, *PsiE, *T1, *T2, *dFdK, *Bbar, *Abar, *Bm;
   const double* Z; const double* alpha;
-  double* gs; double* gK; unsigned* bar;
+  double* gs; double* gK;
   DotJobs jobs;
   double beta, sf2, Dd, Nglob, jitA;
-  int M, Q, regimeA, refine, dd, stop;
+  int M, Q, regimeA, refine, dd;
 };
-__device__ __forceinline__ void tail_barrier(unsigned* bar, unsigned target) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();                                                   // release: this workgroup's stores reach memory
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-    __threadfence();                                                   // acquire: later loads of this CU see the other workgroups' stores
+__host__ __device__ inline int tail_items(int stage, int M, int Q, int refine, int dd) {
+  switch (stage) {
+    case 0: return 32;
+    case 1: return 16 + (dd ? 64 : 16);
+    case 2: return 16 + (refine ? 128 : 0);
+    case 3: return refine ? 16 : 0;
+    case 4: return 32;
+    case 5: return 7 * DOT_BLOCKS + (M + 1) / 2;
+    default: return 1 + Q;
   }
-  __syncthreads();
-  __builtin_amdgcn_s_dcache_inv();
 }
-__global__ void __launch_bounds__(256, 1) gs_tail128_kernel(TailP p) {
+__global__ void __launch_bounds__(256, 1) tail_stage_kernel(TailP p, int stage) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* sA = sm;
   double* sB = sm + SmallImg<FREE_CONTIG>::DOUBLES;
-  double* red = sm;                                     // the stages without tile products reuse the front of the images
+  double* red = sm;                                     // the items without tile products reuse the front of the images
   constexpr int Mp = 128, Dp = 128;
   constexpr long mm = (long)Mp * Mp;
-  const int wg = blockIdx.x;
-  unsigned stage = 0;
+  const int t = blockIdx.x;
   double* Ki = p.Inv;
   double* P = p.Inv + mm;
   GemmP g;
   g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
-  // S1: [Ki ; P] = X^T X for both factors (32 tiles)
-  {
-    GemmP r = g;
-    r.A = p.Linv; r.lda = Mp; r.sA = mm; r.B = p.Linv; r.ldb = Mp; r.sB = mm; r.C = p.Inv; r.ldc = Mp; r.sC = mm; r.K = Mp;
-    for (int t = wg; t < 32; t += TAIL_WGS) gemm32_tile<FREE_CONTIG, FREE_CONTIG>(r, t & 3, (t >> 2) & 3, t >> 4, sA, sB);
-  }
-  tail_barrier(p.bar, TAIL_WGS * ++stage);
-  if (p.stop == (int)stage) return;
-  // S2: E = P C (16 tiles)  |  T2 = Ki Psi2, accumulated in double-double (32 blocks) or on the matrix core (16 tiles)
-  {
-    GemmP e = g;
-    e.K = Mp; e.A = P; e.lda = Mp; e.B = p.C; e.ldb = Dp; e.C = p.E; e.ldc = Dp;
-    GemmP k = g;
-    k.K = Mp; k.A = Ki; k.lda = Mp; k.B = p.Psi2; k.ldb = Mp; k.C = p.T2; k.ldc = Mp;
-    const int n2 = p.dd ? 32 : 16;
-    for (int t = wg; t < 16 + n2; t += TAIL_WGS) {
-      if (t < 16) gemm32_tile<K_CONTIG, FREE_CONTIG>(e, t & 3, t >> 2, 0, sA, sB);
-      else if (p.dd) ddacc_block<2, 8>(Ki, (long)Mp, p.Psi2, (long)Mp, Mp, p.T2, (long)Mp, (t - 16) & 1, (t - 16) >> 1);
-      else gemm32_tile<K_CONTIG, FREE_CONTIG>(k, (t - 16) & 3, (t - 16) >> 2, 0, sA, sB);
+  if (stage == 0) {
+    g.A = p.Linv; g.lda = Mp; g.sA = mm; g.B = p.Linv; g.ldb = Mp; g.sB = mm; g.C = p.Inv; g.ldc = Mp; g.sC = mm; g.K = Mp;
+    gemm32_tile<FREE_CONTIG, FREE_CONTIG>(g, t & 3, (t >> 2) & 3, t >> 4, sA, sB);
+  } else if (stage == 1) {
+    if (t < 16) {
+      g.K = Mp; g.A = P; g.lda = Mp; g.B = p.C; g.ldb = Dp; g.C = p.E; g.ldc = Dp;
+      gemm32_tile<K_CONTIG, FREE_CONTIG>(g, t & 3, t >> 2, 0, sA, sB);
+    } else if (p.dd) {
+      // one row per wave: the rows are independent, so the bits are those of the two-rows-per-wave form; 4 us faster at M = 128 (profiles/r04_dd_variants.txt)
+      ddacc_block<1, 8>(Ki, (long)Mp, p.Psi2, (long)Mp, Mp, p.T2, (long)Mp, (t - 16) & 1, (t - 16) >> 1);
+    } else {
+      g.K = Mp; g.A = Ki; g.lda = Mp; g.B = p.Psi2; g.ldb = Mp; g.C = p.T2; g.ldc = Mp;
+      gemm32_tile<K_CONTIG, FREE_CONTIG>(g, (t - 16) & 3, (t - 16) >> 2, 0, sA, sB);
     }
-  }
-  tail_barrier(p.bar, TAIL_WGS * ++stage);
-  if (p.stop == (int)stage) return;
-  // S3: dFdK(tmp) = T2 Ki (16 tiles)  |  R = C - A E in double-double, one row per item, into PsiE (rows >= M: zero)
-  {
-    GemmP k = g;
-    k.K = Mp; k.A = p.T2; k.lda = Mp; k.B = Ki; k.ldb = Mp; k.C = p.dFdK; k.ldc = Mp;
-    const int nrows = p.refine ? Mp : 0;
-    double (*ph)[128] = reinterpret_cast<double (*)[128]>(red);
-    double (*pl)[128] = reinterpret_cast<double (*)[128]>(red + 3 * 128);
-    for (int t = wg; t < 16 + nrows; t += TAIL_WGS) {
-      if (t < 16) gemm32_tile<K_CONTIG, FREE_CONTIG>(k, t & 3, t >> 2, 0, sA, sB);
-      else {
-        const int m = t - 16;
-        if (m < p.M) residual_row256(m, p.Keep, p.Psi2, p.beta, p.jitA, p.C, p.E, p.M, Mp, Dp, p.PsiE, ph, pl);
-        else if (threadIdx.x < Dp) p.PsiE[(long)m * Dp + threadIdx.x] = 0.0;
-      }
+  } else if (stage == 2) {
+    if (t < 16) {
+      g.K = Mp; g.A = p.T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = p.dFdK; g.ldc = Mp;
+      gemm32_tile<K_CONTIG, FREE_CONTIG>(g, t & 3, t >> 2, 0, sA, sB);
+    } else {
+      const int m = t - 16;
+      double (*ph)[128] = reinterpret_cast<double (*)[128]>(red);
+      double (*pl)[128] = reinterpret_cast<double (*)[128]>(red + 3 * 128);
+      if (m < p.M) residual_row256(m, p.Keep, p.Psi2, p.beta, p.jitA, p.C, p.E, p.M, Mp, Dp, p.PsiE, ph, pl);
+      else if (threadIdx.x < Dp) p.PsiE[(long)m * Dp + threadIdx.x] = 0.0;
     }
-  }
-  tail_barrier(p.bar, TAIL_WGS * ++stage);
-  if (p.stop == (int)stage) return;
-  // S4: E += P R
-  if (p.refine) {
-    GemmP e = g;
-    e.K = Mp; e.A = P; e.lda = Mp; e.B = p.PsiE; e.ldb = Dp; e.C = p.E; e.ldc = Dp; e.beta = 1.0;
-    for (int t = wg; t < 16; t += TAIL_WGS) gemm32_tile<K_CONTIG, FREE_CONTIG>(e, t & 3, t >> 2, 0, sA, sB);
-    tail_barrier(p.bar, TAIL_WGS * ++stage);
-  if (p.stop == (int)stage) return;
-  }
-  // S5: PsiE = Psi2 E (16 tiles)  |  T1 = E E^T (16 tiles)
-  {
-    GemmP a = g;
-    a.K = Mp; a.A = p.Psi2; a.lda = Mp; a.B = p.E; a.ldb = Dp; a.C = p.PsiE; a.ldc = Dp;
-    GemmP b = g;
-    b.K = Dp; b.A = p.E; b.lda = Dp; b.B = p.E; b.ldb = Dp; b.C = p.T1; b.ldc = Mp;
-    for (int t = wg; t < 32; t += TAIL_WGS) {
-      if (t < 16) gemm32_tile<K_CONTIG, FREE_CONTIG>(a, t & 3, t >> 2, 0, sA, sB);
-      else gemm32_tile<K_CONTIG, K_CONTIG>(b, (t - 16) & 3, (t - 16) >> 2, 0, sA, sB);
+  } else if (stage == 3) {
+    g.K = Mp; g.A = P; g.lda = Mp; g.B = p.PsiE; g.ldb = Dp; g.C = p.E; g.ldc = Dp; g.beta = 1.0;
+    gemm32_tile<K_CONTIG, FREE_CONTIG>(g, t & 3, t >> 2, 0, sA, sB);
+  } else if (stage == 4) {
+    // the tile product, then the assembled outputs that need nothing but this tile and finished inputs: every element of the assembly is
+    // computed once, by the expression of assemble_elem
+    const int tt = t & 15, bx = tt & 3, by = tt >> 2;
+    if (t < 16) {
+      g.K = Mp; g.A = p.Psi2; g.lda = Mp; g.B = p.E; g.ldb = Dp; g.C = p.PsiE; g.ldc = Dp;
+      gemm32_tile<K_CONTIG, FREE_CONTIG>(g, bx, by, 0, sA, sB);
+      for (int e = threadIdx.x; e < ST * ST; e += 256)      // Abar and Bm's lower block: only E (finished in stage 3)
+        assemble_elem(mm + (long)(by * ST + (e >> 5)) * Dp + bx * ST + (e & 31), Ki, P, p.T1, p.dFdK, p.E, p.beta, p.Dd, Mp, Dp, p.Bbar, p.dFdK, p.Abar, p.Bm);
+    } else {
+      g.K = Dp; g.A = p.E; g.lda = Dp; g.B = p.E; g.ldb = Dp; g.C = p.T1; g.ldc = Mp;
+      gemm32_tile<K_CONTIG, K_CONTIG>(g, bx, by, 0, sA, sB);
+      __syncthreads();                                      // the tile of E E^T this workgroup just stored (same CU: visible after the barrier)
+      for (int e = threadIdx.x; e < ST * ST; e += 256)
+        assemble_elem((long)(by * ST + (e >> 5)) * Mp + bx * ST + (e & 31), Ki, P, p.T1, p.dFdK, p.E, p.beta, p.Dd, Mp, Dp, p.Bbar, p.dFdK, p.Abar, p.Bm);
     }
-  }
-  tail_barrier(p.bar, TAIL_WGS * ++stage);
-  if (p.stop == (int)stage) return;
-  // S6: the assembled partials and the phase-2 operand
-  for (long idx = wg * 256L + threadIdx.x; idx < mm + (long)Mp * Dp; idx += TAIL_WGS * 256L)
-    assemble_elem(idx, Ki, P, p.T1, p.dFdK, p.E, p.beta, p.Dd, Mp, Dp, p.Bbar, p.dFdK, p.Abar, p.Bm);
-  tail_barrier(p.bar, TAIL_WGS * ++stage);
-  if (p.stop == (int)stage) return;
-  // S7: the seven traces (jobs x 64 blocks)  |  K_mm parts of grad_Z / grad_alpha, two rows per pass (alpha partials per row through T2)
-  {
-    double* dpart = p.gs + GS_COUNT + 8;
-    const int nd = p.jobs.n * DOT_BLOCKS, nk = (p.M + 1) / 2;
-    for (int t = wg; t < nd + nk; t += TAIL_WGS) {
-      if (t < nd) dots_block(p.jobs, dpart, t % DOT_BLOCKS, t / DOT_BLOCKS, red);
-      else {
-        const int half = threadIdx.x >> 7, j = 2 * (t - nd) + half;
-        kmm_grads_row(j, j < p.M, threadIdx.x & 127, red + 2 * KG_QC * half, p.dFdK, p.Keep, p.Bbar, p.Psi2, p.Z, p.alpha, p.M, Mp, p.Q, p.regimeA,
-                      p.gK, p.T2);
-      }
+  } else if (stage == 5) {
+    const int nd = p.jobs.n * DOT_BLOCKS;
+    if (t < nd) dots_block(p.jobs, p.gs + GS_COUNT + 8, t % DOT_BLOCKS, t / DOT_BLOCKS, red);
+    else {
+      const int half = threadIdx.x >> 7, j = 2 * (t - nd) + half;
+      kmm_grads_row(j, j < p.M, threadIdx.x & 127, red + 2 * KG_QC * half, p.dFdK, p.Keep, p.Bbar, p.Psi2, p.Z, p.alpha, p.M, Mp, p.Q, p.regimeA,
+                    p.gK, p.T2);
     }
+  } else {
+    if (t == 0) scalars_block(p.sc, p.gs, p.jobs, p.gs + GS_COUNT + 8, p.beta, p.sf2, p.Dd, p.Nglob);
+    else colsum_block(p.T2, p.M, p.Q, p.gK + (long)p.M * p.Q, t - 1, red);
   }
-  tail_barrier(p.bar, TAIL_WGS * ++stage);
-  if (p.stop == (int)stage) return;
-  // S8: F, grad_beta, grad_sf2  |  column sums of the alpha partials
-  if (wg == 0) scalars_block(p.sc, p.gs, p.jobs, p.gs + GS_COUNT + 8, p.beta, p.sf2, p.Dd, p.Nglob);
-  else for (int q = wg - 1; q < p.Q; q += TAIL_WGS - 1) colsum_block(p.T2, p.M, p.Q, p.gK + (long)p.M * p.Q, q, red);
 }
 std::atomic<int> g_opt_gs_tail{env_on("GPARML_GS_TAIL") ? 1 : 0};
 
@@ -581,19 +554,17 @@ int run_global_step(gp_ctx* c) {
   hipLaunchKernelGGL(build_kmm_kernel, dim3(1024), dim3(256), 0, st, c->Z, c->alpha, c->sf2, c->beta, Psi2, M, Mp, Q, c->Kmm, c->Kmm + mm,
                      c->KmmKeep, (c->jitter_mask & 1) ? 1e-7 : 0.0, (c->jitter_mask & 2) ? 1e-7 : 0.0, c->gs);
   GP_HIP(c, hipGetLastError());
-  // one-panel problems (M, D <= 128): the panel kernel, then everything else in one persistent launch (gs_tail128_kernel)
+  // one-panel problems (M, D <= 128): the panel kernel, then seven launches of tail_stage_kernel instead of fifteen kernels
   if (Mp == NB && Dp == NB && g_opt_gs_tail.load()) {
     GP_HIP(c, hipFuncSetAttribute((const void*)potrf_trinv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS_DOUBLES * 8));
-    GP_HIP(c, hipFuncSetAttribute((const void*)gs_tail128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_DOUBLES * 8));
+    GP_HIP(c, hipFuncSetAttribute((const void*)tail_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_DOUBLES * 8));
     hipLaunchKernelGGL(potrf_trinv128_kernel, dim3(2), dim3(512), POTRF_LDS_DOUBLES * 8, st, c->Kmm, (long)Mp, mm, 0, c->Linv, failf, c->gs + GS_LOGDET_K);
     TailP t;
     t.Linv = c->Linv; t.Inv = c->Inv; t.Psi2 = Psi2; t.C = C; t.sc = sc; t.Keep = c->KmmKeep;
     t.E = c->E; t.PsiE = c->PsiE; t.T1 = c->T1; t.T2 = c->T2; t.dFdK = c->dFdK; t.Bbar = c->Bbar; t.Abar = c->Abar; t.Bm = c->Bm;
     t.Z = c->Z; t.alpha = c->alpha; t.gs = c->gs; t.gK = c->gK;
-    t.bar = reinterpret_cast<unsigned*>(c->gs + GS_COUNT + 4);     // a spare failure-flag slot: zeroed by build_kmm_kernel above
     t.beta = c->beta; t.sf2 = c->sf2; t.Dd = (double)D; t.Nglob = (double)c->N_global; t.jitA = (c->jitter_mask & 2) ? 1e-7 : 0.0;
     t.M = M; t.Q = Q; t.regimeA = c->regime_A ? 1 : 0; t.refine = g_opt_refine_E.load(); t.dd = g_opt_dd_kipsi2.load();
-    { const char* e = getenv("GPARML_TAIL_STOP"); t.stop = e ? atoi(e) : 0; }
     t.jobs.n = 7;
     t.jobs.j[0] = {c->Inv, Psi2, Mp, M, M, GS_TR_KIPSI2};
     t.jobs.j[1] = {c->Inv + mm, Psi2, Mp, M, M, GS_TR_PPSI2};
@@ -602,7 +573,12 @@ int run_global_step(gp_ctx* c) {
     t.jobs.j[4] = {c->dFdK, c->KmmKeep, Mp, M, M, GS_SUM_V};
     t.jobs.j[5] = {c->Abar, C, Dp, M, D, GS_SUM_AC};
     t.jobs.j[6] = {c->Bbar, Psi2, Mp, M, M, GS_SUM_BPSI2};
-    hipLaunchKernelGGL(gs_tail128_kernel, dim3(TAIL_WGS), dim3(256), TAIL_LDS_DOUBLES * 8, st, t);
+    for (int stage = 0; stage < TAIL_STAGES; ++stage) {
+      const int items = tail_items(stage, M, Q, t.refine, t.dd);
+      // only the stages with tile products need the operand images
+      const size_t lds = (stage <= 4) ? (size_t)TAIL_LDS_DOUBLES * 8 : 4096;
+      if (items > 0) hipLaunchKernelGGL(tail_stage_kernel, dim3(items), dim3(256), lds, st, t, stage);
+    }
     GP_HIP(c, hipGetLastError());
     c->gs_pending = true;
     return GP_OK;

@@ -213,24 +213,33 @@ __global__ void __launch_bounds__(256) p1v2_reduce_kernel(const double* __restri
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < SC_COUNT)
     sc[threadIdx.x] = threadIdx.x == SC_SUM_YYT ? sumYY : threadIdx.x == SC_PSI0 ? psi0 : threadIdx.x == SC_NLOCAL ? nlocal : 0.0;
   const P1Out o = outs[blockIdx.y];
-  const int e = blockIdx.x * 256 + threadIdx.x;   // element of the 128x128 tile
+  // 32 elements of the 128 x 128 tile per workgroup, eight threads per element: thread u owns the partial sum over the slices u, u + 8, u + 16, ...
+  // (in that order, eight loads in flight), and the eight partial sums are combined as ((0+1)+(2+3))+((4+5)+(6+7)) -- the arithmetic of the
+  // one-thread-per-element form this replaces (r02: acc[u] += slice(sl + u) for sl = 0, 8, ...), with eight times the loads in flight: the
+  // long serial chain (nslices / 8 round trips per thread) was 13 us at configs[1]'s size
+  __shared__ double comb[8][32];
+  const int el = threadIdx.x & 31, u = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;             // element of the 128x128 tile
   const int r = e >> 7, c = e & 127;
-  if (o.kind == 1 && c < r) return;               // filled by its mirror image
-  if (o.kind == 2 && c >= Dp) return;
-  // eight independent partial sums (slices sl, sl + 8, ...) so that eight loads are in flight; the order is fixed
-  double s = 0.0;
-  if (o.kind != 2 || c < o.ncols) {
+  const bool skip = (o.kind == 1 && c < r) || (o.kind == 2 && c >= Dp);      // filled by its mirror image / beyond the padded width
+  double acc = 0.0;
+  if (!skip && (o.kind != 2 || c < o.ncols)) {
     const double* src = part + (long)o.first * (TILE * TILE) + e;
     const long step = (long)o.stride * (TILE * TILE);
-    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    int sl = 0;
-    for (; sl + 8 <= o.nslices; sl += 8) {
+    int sl = u;
+    for (; sl + 8 * 7 < o.nslices; sl += 8 * 8) {
+      double x[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += src[(long)(sl + u) * step];
+      for (int j = 0; j < 8; ++j) x[j] = src[(long)(sl + 8 * j) * step];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += x[j];
     }
-    for (int u = 0; sl < o.nslices; ++sl, ++u) acc[u] += src[(long)sl * step];
-    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; sl < o.nslices; sl += 8) acc += src[(long)sl * step];
   }
+  comb[u][el] = acc;
+  __syncthreads();
+  if (u != 0 || skip) return;
+  const double s = ((comb[0][el] + comb[1][el]) + (comb[2][el] + comb[3][el])) + ((comb[4][el] + comb[5][el]) + (comb[6][el] + comb[7][el]));
   if (o.kind == 2) {
     C[((long)o.ti * TILE + r) * Dp + c] = s;
   } else {
@@ -338,7 +347,7 @@ int run_phase1_v2(gp_ctx* c) {
   GP_HIP(c, hipGetLastError());
   double* Psi2 = c->stats;
   double* C = c->stats + (long)c->Mp * c->Mp;
-  hipLaunchKernelGGL(p1v2_reduce_kernel, dim3(TILE * TILE / 256, pl->nouts), dim3(256), 0, c->stream, c->part, pl->outs, Psi2, C, c->Mp, c->Dp,
+  hipLaunchKernelGGL(p1v2_reduce_kernel, dim3(TILE * TILE / 32, pl->nouts), dim3(256), 0, c->stream, c->part, pl->outs, Psi2, C, c->Mp, c->Dp,
                      c->sumYY, c->sf2 * (double)c->N, (double)c->N, C + (long)c->Mp * c->Dp);
   GP_HIP(c, hipGetLastError());
   return GP_OK;

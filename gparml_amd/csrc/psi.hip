@@ -1194,7 +1194,21 @@ __global__ void __launch_bounds__(256) p2_reduce_kernel(const double* __restrict
     // 8 columns x 32 part-lanes per pass
     const int c = c0 + (threadIdx.x & 7), pl = threadIdx.x >> 3;
     double s = 0.0;
-    if (c < CXp) for (int i = pl; i < nparts; i += 32) s += Rpart[((long)i * Mp + m) * CXp + c];
+    if (c < CXp) {
+      // eight loads in flight, added in the order of the plain loop (hipcc compiled that one as load, wait, add: one memory round trip per
+      // partial, 24 in a row at configs[1]'s size)
+      const double* src = Rpart + (long)m * CXp + c;
+      const long step = (long)Mp * CXp;
+      int i = pl;
+      for (; i + 32 * 7 < nparts; i += 32 * 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = src[(long)(i + 32 * u) * step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+      }
+      for (; i < nparts; i += 32) s += src[(long)i * step];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int k = 128; k >= 8; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
@@ -1264,8 +1278,20 @@ __global__ void colsum2_kernel(const double* __restrict__ a, int rows_a, int lda
   const int q = blockIdx.x;
   __shared__ double red[256];
   double s = 0.0;
-  for (int r = threadIdx.x; r < rows_a; r += 256) s += a[(long)r * lda + q];
-  if (b) for (int r = threadIdx.x; r < rows_b; r += 256) s += b[(long)r * ldb + q];
+  // eight loads in flight, added in the order of the plain loop (which compiles to one memory round trip per element)
+  auto strided = [&](const double* __restrict__ x, int rows, int ld) {
+    int r = threadIdx.x;
+    for (; r + 256 * 7 < rows; r += 256 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(long)(r + 256 * u) * ld + q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < rows; r += 256) s += x[(long)r * ld + q];
+  };
+  strided(a, rows_a, lda);
+  if (b) strided(b, rows_b, ldb);
   red[threadIdx.x] = s;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }

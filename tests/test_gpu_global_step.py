@@ -254,9 +254,10 @@ def test_fixed_embedding_preparation_cache_follows_the_hyper_parameters():
 
 @pytest.mark.parametrize('N,D,M,Q,regime,emb', [(100000, 10, 128, 10, 'A', False), (100000, 10, 128, 10, 'A', True), (20000, 10, 128, 10, 'B', True),
                                               (3000, 5, 70, 4, 'A', False), (900, 128, 33, 11, 'B', True), (2000, 1, 1, 1, 'A', False)])
-def test_fused_one_panel_tail_is_bit_identical_to_the_separate_launches(N, D, M, Q, regime, emb):
-    """M, D <= 128 (BASELINE configs[1] is M = 128, D = 10): everything of the global step behind the panel factorisation runs as ONE persistent
-    kernel (gs_tail128_kernel, csrc/linalg.hip: eight stages behind agent-scope barriers) instead of fifteen launches.  The stages call the same
+def test_short_one_panel_tail_is_bit_identical_to_the_fifteen_launches(N, D, M, Q, regime, emb):
+    """M, D <= 128 (BASELINE configs[1] is M = 128, D = 10): everything of the global step behind the panel factorisation runs as SEVEN launches
+    of one kernel (tail_stage_kernel, csrc/linalg.hip: products that do not depend on each other share a launch, the assembly rides on the
+    tiles it needs) instead of fifteen kernels.  The stages call the same
     device functions as the separate kernels, so the bound, every gradient, the partials (partial_terms.py:102-138) and the inverses
     (partial_terms.py:60, 95) must agree BIT FOR BIT with the library run with the fused kernel switched off (gp_debug_set_option('gs_tail', 0)),
     also without the two extended-precision pieces, and on a repeated evaluation."""

@@ -58,6 +58,7 @@ SIGNATURES = {
     'gp_set_local_statistics': (ctypes.c_int, [_vp, ctypes.c_double, _dp, _dp, ctypes.c_double, ctypes.c_double]),
     'gp_last_timings': (ctypes.c_int, [_vp, _dp]),
     'gp_set_timing': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'gp_i8_status': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), _dp, _dp, _dp, ctypes.POINTER(_i64)]),
     'gp_memory_info': (ctypes.c_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     'gp_grad_from_parts': (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     'gp_cg_set_grads': (ctypes.c_int, [_vp]),

@@ -200,6 +200,16 @@ extern "C" int gp_memory_info(gp_ctx* c, int64_t* free_bytes, int64_t* total_byt
   return GP_OK;
 }
 
+extern "C" int gp_i8_status(gp_ctx* c, int* state, double* rel_psi2, double* rel_c, double* cond_lower_bound, int64_t* checks) {
+  if (!c) return GP_ERR_BAD_ARG;
+  if (state) *state = !p1i8_applicable_static(c) ? -1 : c->i8_guard;
+  if (rel_psi2) *rel_psi2 = c->i8_rel_psi2;
+  if (rel_c) *rel_c = c->i8_rel_c;
+  if (cond_lower_bound) *cond_lower_bound = c->i8_cond_lb;
+  if (checks) *checks = c->i8_checks;
+  return GP_OK;
+}
+
 extern "C" int gp_set_timing(gp_ctx* c, int level) {
   if (!c) return GP_ERR_BAD_ARG;
   if (level < 0 || level > 2) return fail(c, GP_ERR_BAD_ARG, "gp_set_timing: level must be 0 (no events), 1 (total only) or 2 (every phase and kernel)");
@@ -269,6 +279,7 @@ extern "C" int gp_upload_shard(gp_ctx* c, const double* Y, const double* X_mu, c
   c->have_dir = false;
   c->prep_fixa_valid = false;
   c->i8_y_valid = false;
+  c->i8_guard = 0; c->i8_since_check = 0; c->i8_check_pending = false;      // new data: the int8 path is measured again (p1i8.hip, guard)
   return GP_OK;
 }
 
@@ -677,6 +688,7 @@ extern "C" int gp_finish(gp_ctx* c, double* F, double* grad_Z, double* grad_sf2,
   if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_finish before gp_global_step");
   GP_HIP(c, hipSetDevice(c->device));
   const bool want_grads = grad_Z || grad_alpha;
+  if (c->i8_check_pending) GP_TRY(p1i8_check_finish(c));      // this evaluation ran both phase-1 paths: decide whether the context stays on int8
   if (want_grads && c->state < 3) {
     GP_TRY(check_global(c));   // a failed global step is the more useful message
     return fail(c, GP_ERR_STATE, "gp_finish: gradients requested before gp_phase2");

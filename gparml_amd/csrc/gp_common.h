@@ -97,6 +97,12 @@ struct gp_ctx {
   bool i8_active = false;     // this evaluation's phase 1 runs on the int8 matrix core (psi1_kernel wrote the digits)
   bool i8_y_valid = false;    // Y's digits are current (reset by gp_upload_shard)
   bool i8_unsupported = false;  // the int8 plan could not be built for this context (falls back to the float64 kernels)
+  // the int8 path's run-time guard (p1i8.hip, "guard"): 0 = not checked since the last upload, 1 = accepted, 2 = rejected (float64 from then on)
+  int i8_guard = 0;
+  bool i8_check_pending = false;   // this evaluation ran both phase-1 paths: gp_finish reads the comparison and decides
+  long i8_since_check = 0, i8_checks = 0;
+  double i8_rel_psi2 = 0, i8_rel_c = 0, i8_cond_lb = 0;
+  double* i8_cmp = nullptr;        // device: [4] squared Frobenius norms (dPsi2, Psi2, dC, C) | [2] max diag(Psi2), max diag(P) | partials
   int* bmap = nullptr;        // phase-1 block -> (slice, tile type) placement table
   int bmap_T = -1, bmap_S = -1, bmap_blocks = 0;
   double* klpart = nullptr;   // [blocks] partial KL sums
@@ -207,8 +213,12 @@ int run_phase2(gp_ctx* c);
 bool p2_fast_mode(const gp_ctx* c);
 // p1i8.hip (regime A phase 1 on the int8 matrix core)
 bool p1i8_applicable(const gp_ctx* c);
+bool p1i8_applicable_static(const gp_ctx* c);     // the shape / regime conditions alone (not the opt-in switch, not the guard)
 int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ, double** Dpart, int row_blocks);
 int run_phase1_i8(gp_ctx* c);
+int p1i8_check_begin(gp_ctx* c);      // after run_phase1_i8: keep the int8 statistics aside (the caller then runs the float64 phase 1)
+int p1i8_check_compare(gp_ctx* c);    // after the float64 phase 1: norms of the difference (device)
+int p1i8_check_finish(gp_ctx* c);     // gp_finish, after the stream synchronisation of a checked evaluation: decide
 void p1i8_free(gp_ctx* c);
 // p1v2.hip (regime A phase 1 without wasted tile slots)
 bool p1v2_applicable(const gp_ctx* c);

@@ -559,6 +559,16 @@ int run_phase1(gp_ctx* c) {
     // fixed embeddings on the int8 matrix core: exact integer products of the 35-bit digits psi1_kernel wrote (p1i8.hip)
     int rc = run_phase1_i8(c);
     if (rc != GP_OK) return rc;
+    // the guard (p1i8.hip): the first int8 evaluation after an upload and every 64th one also run the float64 phase 1, compare the two sets of
+    // statistics on the device and carry on with the float64 ones; gp_finish decides whether the context stays on the int8 path
+    if (c->i8_guard == 0 || ++c->i8_since_check >= 64) {
+      GP_TRY_RC(p1i8_check_begin(c));
+      c->i8_active = false;                         // the float64 phase 1 this shape takes by default (p1v2_kernel or the tile kernel)
+      const int rc64 = run_phase1(c);
+      c->i8_active = true;
+      if (rc64 != GP_OK) return rc64;
+      return p1i8_check_compare(c);
+    }
     hipLaunchKernelGGL(p1_scalars_kernel, dim3(1), dim3(256), 0, c->stream, c->klpart, c->kl_blocks, c->sumYY, c->sf2, (double)c->N,
                        1, c->stats + (long)c->Mp * c->Mp + (long)c->Mp * c->Dp);
     GP_HIP(c, hipGetLastError());

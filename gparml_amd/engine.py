@@ -256,6 +256,13 @@ class ShardEngine(object):
         self._ck(self.lib.gp_set_local_statistics(self.h, float(sum_YYT), p2, pc, float(sum_exp_K_ii), float(KL)),
                  'gp_set_local_statistics')
 
+    def i8_status(self):
+        """The int8 phase-1 guard (gp_i8_status): {'state': -1 n/a | 0 unchecked | 1 accepted | 2 rejected, 'rel_psi2', 'rel_c', 'cond_lower_bound', 'checks'}."""
+        st, ck = ctypes.c_int(), ctypes.c_int64()
+        r2, rc, cl = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._ck(self.lib.gp_i8_status(self.h, ctypes.byref(st), ctypes.byref(r2), ctypes.byref(rc), ctypes.byref(cl), ctypes.byref(ck)), 'gp_i8_status')
+        return {'state': st.value, 'rel_psi2': r2.value, 'rel_c': rc.value, 'cond_lower_bound': cl.value, 'checks': ck.value}
+
     def set_timing(self, level):
         """HIP timing events per evaluation: 2 = every stage and dominant kernel (default), 1 = first and last only (total_ms), 0 = none.
         Each event is ~4-7 us of idle stream; an optimiser on a small problem (BASELINE configs[1]) switches them off."""

@@ -175,6 +175,12 @@ int gp_last_timings(gp_ctx* ctx, double* out8);
  * on (~4-7 us of idle stream each, thirteen per evaluation): nothing at configs[2]'s size, 15 % of an evaluation at configs[1]'s.  An optimiser
  * that does not read the timings switches them off. */
 int gp_set_timing(gp_ctx* ctx, int level);
+/* The opt-in int8 phase 1 (GPARML_P1_I8=1; csrc/p1i8.hip: Psi2 / Psi1^T Y of partial_terms.py:45-52, 79-80 from exact integer digit products) guards
+ * itself: the first int8 evaluation after an upload and every 64th one run both phase-1 paths, compare the statistics on the device and use the
+ * float64 ones; the context is taken off the int8 path (until the next upload) when cond_lower_bound * max(rel_psi2, rel_c) exceeds the library's
+ * threshold.  state: -1 the path does not apply to this context's shape / regime, 0 not checked yet, 1 accepted, 2 rejected (float64 kernels run);
+ * rel_*: relative Frobenius distance of the int8 statistics from the float64 ones at the last check; checks: how many were made. */
+int gp_i8_status(gp_ctx* ctx, int* state, double* rel_psi2, double* rel_c, double* cond_lower_bound, int64_t* checks);
 /* hipMemGetInfo of ctx's device: bytes free / total right now (the footprint of a shard at BASELINE configs[4]'s per-GPU size is
  * OBSERVED with this; the reference has no counterpart -- its shard lives in the mapper process' numpy arrays,
  * local_MapReduce.py:197-201) */

@@ -30,6 +30,12 @@ def _eval(d, N, D, M, Q, i8):
         eng = ShardEngine(N, D, M, Q)
         eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
         eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        if i8:
+            # the first int8 evaluation after an upload is the guard's check (both phase-1 paths, float64 statistics used): accepted here
+            eng.evaluate(False)
+            st = eng.i8_status()
+            assert st['state'] == 1 and st['checks'] == 1 and 0 < st['rel_psi2'] < 1e-9 and 0 < st['rel_c'] < 1e-9 and st['cond_lower_bound'] > 1, st
+            assert st['cond_lower_bound'] * max(st['rel_psi2'], st['rel_c']) <= 1e-4, st
         out = eng.evaluate(False)
         out['Psi2'], out['C'] = eng.download('PSI2_SUM'), eng.download('PSI1TY')
         out['timings'] = eng.timings()
@@ -76,13 +82,17 @@ def test_int8_sums_do_not_depend_on_the_slicing():
     engines = []
     try:
         one = ShardEngine(N, D, M, Q); engines.append(one)
-        one.upload_shard(d['Y'], d['X_mu'], d['X_S']); one.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta']); one.phase1()
+        one.upload_shard(d['Y'], d['X_mu'], d['X_S']); one.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        one.evaluate(False); assert one.i8_status()['state'] == 1          # the guard's check (float64 statistics); from here on int8
+        one.phase1()
         P1, C1 = one.download('PSI2_SUM'), one.download('PSI1TY')
         cut = 70001
         parts = []
         for sl in (slice(0, cut), slice(cut, N)):
             e = ShardEngine(sl.stop - sl.start, D, M, Q); engines.append(e)
-            e.upload_shard(d['Y'][sl], d['X_mu'][sl], d['X_S'][sl]); e.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N); e.phase1()
+            e.upload_shard(d['Y'][sl], d['X_mu'][sl], d['X_S'][sl]); e.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
+            e.evaluate(False); assert e.i8_status()['state'] == 1
+            e.phase1()
             parts.append(e)
         parts[0].combine(parts[1], 'stats', 'add')
         P2, C2 = parts[0].download('PSI2_SUM'), parts[0].download('PSI1TY')
@@ -111,3 +121,49 @@ def test_int8_phase1_against_the_long_double_truth():
     for k, (e8, e64) in rep.items():
         assert e8 <= 1e-5, (k, e8)
     assert rep['grad_Z'][0] <= 1e-6
+
+
+def test_the_guard_measures_accepts_rejects_and_resets():
+    """csrc/p1i8.hip "guard": the first int8 evaluation after an upload runs BOTH phase-1 paths, compares the statistics on the device and uses the
+    float64 ones -- so its results are, bit for bit, those of the float64 library; gp_i8_status reports the measured distances and the lower bound
+    of cond(K_mm + beta Psi2); an accepted context then runs on the int8 statistics (different bits, same numbers to 2e-6); a rejected one (test
+    hook: threshold 0) keeps the float64 kernels -- bit-identical to the float64 library -- until the next upload resets the state."""
+    from gparml_amd.engine import ShardEngine
+    from oracle import factorised as Fz
+    N, D, M, Q = 70000, 100, 512, 10
+    d = Fz.synthetic_shard(N, D, M, Q, regime='A', seed=11, zseed=12, alpha_value=0.4)
+    lib = _lib()
+    keys = ('F', 'grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta')
+    same = lambda a, b: all(np.array_equal(np.asarray(a[k]), np.asarray(b[k])) for k in keys)
+    eng = ShardEngine(N, D, M, Q)
+    try:
+        eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+        eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        ref = eng.evaluate(False)                                   # the float64 library
+        assert eng.i8_status()['state'] == 0 and eng.i8_status()['checks'] == 0
+        assert lib.gp_debug_set_option(b'p1_i8', 1) == 0
+        chk = eng.evaluate(False)                                   # the check: both paths, float64 statistics
+        st = eng.i8_status()
+        assert same(chk, ref) and st['state'] == 1 and st['checks'] == 1, st
+        assert st['cond_lower_bound'] * max(st['rel_psi2'], st['rel_c']) <= 1e-4
+        i8 = eng.evaluate(False)                                    # accepted: int8 statistics
+        assert not same(i8, ref) and eng.i8_status()['checks'] == 1
+        for k in keys:
+            assert_close(i8[k], ref[k], 2e-6, what=k + ' int8 vs float64')
+        # new data: measured again; with the threshold at zero the check rejects
+        assert lib.gp_debug_set_option(b'i8_guard_strict', 1) == 0
+        eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+        assert eng.i8_status()['state'] == 0
+        eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        chk2 = eng.evaluate(False)
+        st2 = eng.i8_status()
+        assert same(chk2, ref) and st2['state'] == 2 and st2['checks'] == 2, st2
+        for _ in range(2):
+            assert same(eng.evaluate(False), ref)                   # rejected: the float64 kernels, nothing else
+        assert eng.i8_status()['checks'] == 2
+    finally:
+        lib.gp_debug_set_option(b'i8_guard_strict', 0); lib.gp_debug_set_option(b'p1_i8', 0)
+        eng.close()
+    small = ShardEngine(500, 3, 20, 2)
+    assert small.i8_status()['state'] == -1                         # the path does not apply to this shape
+    small.close()

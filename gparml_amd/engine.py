@@ -241,6 +241,7 @@ class ShardEngine(object):
                 break
             except _lib.JitterRetry as r:
                 jitter = r.mask
+        self.last_jitter = jitter               # 0, or the mask of the matrices that needed the reference's 1e-7 jitter in this evaluation
         if want_embedding_grads:
             out['grad_X_mu'] = self.download('GRAD_X_MU')
             if not self.regime_A_hint:
@@ -266,7 +267,8 @@ class ShardEngine(object):
     def set_timing(self, level):
         """HIP timing events per evaluation: 2 = every stage and dominant kernel (default), 1 = first and last only (total_ms), 0 = none.
         Each event is ~4-7 us of idle stream; an optimiser on a small problem (BASELINE configs[1]) switches them off."""
-        self._ck(self.lib.gp_set_timing(self.h, int(level)), 'gp_set_timing')
+        if hasattr(self.lib, "gp_set_timing"):
+            self._ck(self.lib.gp_set_timing(self.h, int(level)), "gp_set_timing")
 
     def timings(self):
         t = np.zeros(8)

@@ -34,11 +34,17 @@ for (N, D, M, Q, alpha) in SHAPES:
     eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
     eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
     out = eng.evaluate(True)
+    keys = ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S')
+    errs = {k: float(np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))) for k in keys}
+    if abs(out['F'] - ref['F']) > 1e-6 * abs(ref['F']) or max(errs.values()) > 1e-5:
+        # a failure here was seen ONCE in round 5 (grad_Z 1e-4 off at (9000, 3, 200, 6) inside a full-suite run; 0 of 40 repeats since, with the
+        # round-4 library as well: tools/stress_tile.sh): say everything that helps to place it -- the jitter branch, a repeat on the same context
+        again = eng.evaluate(True)
+        errs2 = {k: float(np.max(np.abs(np.asarray(again[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))) for k in keys}
+        print('TILE_FAIL', (N, D, M, Q), 'F', out['F'], ref['F'], 'errors', errs, 'jitter mask', eng.last_jitter, '| repeated on the same context:', errs2,
+              'jitter mask', eng.last_jitter, flush=True)
+        raise SystemExit(1)
     eng.close()
-    assert abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F']), (N, D, M, Q)
-    for k in ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S'):
-        err = np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))
-        assert err <= 1e-5, ((N, D, M, Q), k, err)
     print('TILE_OK', N, D, M, Q)
 '''
 

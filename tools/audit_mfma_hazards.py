@@ -14,6 +14,7 @@ Issue cycles are counted as 16 per MFMA (4 passes) and 4 per other instruction. 
 import re
 import sys
 
+RESULT_WINDOW = 17   # cycles behind an MFMA's issue in which its result must not be read by a non-MFMA instruction (4 passes + write-back)
 WINDOW = 16      # cycles behind the MFMA's issue in which it may still read its operands (4 passes of 4 cycles)
 
 
@@ -29,12 +30,13 @@ def regs(tok):
 def audit(path):
     kern, in_asm = None, False
     recent = []          # (age, line, text, source registers) of the last asm MFMAs
+    results = []         # (age, line, text, destination registers) of the last asm MFMAs: a compiler-generated READ inside the latency window is hazard (c)
     bad = mfmas = 0
     prev_compiler_write = None     # (line, text, dst regs) of the previous instruction if compiler-generated
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         if s.endswith(':') and s.startswith('_Z'):
-            kern, recent, prev_compiler_write = s[:-1], [], None
+            kern, recent, results, prev_compiler_write = s[:-1], [], [], None
         if s.startswith(';;#ASMSTART'):
             in_asm = True
             continue
@@ -46,6 +48,11 @@ def audit(path):
         toks = re.split(r'[ \t]+', s.split(';')[0].strip())
         op = toks[0]
         cost = 16 if op.startswith('v_mfma') else 4
+        if op == 's_nop':
+            try:
+                cost = int(toks[1]) + 1
+            except (IndexError, ValueError):
+                pass
         if in_asm and op.startswith('v_mfma'):
             mfmas += 1
             srcs = set()
@@ -60,9 +67,23 @@ def audit(path):
                         (kern or '?')[:60], ln, s, sorted(prev_compiler_write[2] & srcs), prev_compiler_write[1]))
             recent = [(a + cost, l, t, r) for (a, l, t, r) in recent if a + cost < WINDOW]
             recent.append((0, ln, s, srcc))
+            results = [(a + cost, l, t, r) for (a, l, t, r) in results if a + cost < RESULT_WINDOW]
+            results.append((0, ln, s, regs(toks[1])))
             prev_compiler_write = None
             continue
         dst = regs(toks[1]) if len(toks) > 1 and op.startswith('v_') and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane', 'v_mfma')) else set()
+        if not in_asm and op.startswith(('v_', 'global_store', 'buffer_store', 'flat_store', 'ds_write')) and not op.startswith('v_mfma'):
+            # (c) a compiler-generated instruction READS an asm MFMA's result inside its latency window (the source code puts mfma_drain() = s_nop 15
+            # in front of such reads; a register copy the compiler inserts on its own -- e.g. to merge two branches -- has no such protection)
+            srcs_here = set()
+            for t in toks[2:] if op.startswith('v_') else toks[1:]:
+                srcs_here |= regs(t)
+            for (a, l, t, r) in results:
+                if srcs_here & r:
+                    bad += 1
+                    if bad <= 10:
+                        print('%s line %d: "%s" reads %s, the result of the asm MFMA issued %d cycle(s) earlier (line %d): "%s"' % (
+                            (kern or '?')[:60], ln, s, sorted(srcs_here & r), a, l, t))
         if not in_asm and dst:
             for (a, l, t, r) in recent:
                 if dst & r:
@@ -74,6 +95,7 @@ def audit(path):
         else:
             prev_compiler_write = None
         recent = [(a + cost, l, t, r) for (a, l, t, r) in recent if a + cost < WINDOW]
+        results = [(a + cost, l, t, r) for (a, l, t, r) in results if a + cost < RESULT_WINDOW]
     print('%s: asm MFMAs %d, hazards %d' % (path, mfmas, bad))
     return bad
 

@@ -180,6 +180,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (c->staging) (void)hipFree(c->staging);
   gp::p1v2_free(c);
   gp::p1i8_free(c);
+  gp::p2i8_free(c);
   gp::comm_free(c);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 4; ++i) if (c->gev[i]) (void)hipEventDestroy(c->gev[i]);
@@ -279,6 +280,7 @@ extern "C" int gp_upload_shard(gp_ctx* c, const double* Y, const double* X_mu, c
   c->have_dir = false;
   c->prep_fixa_valid = false;
   c->i8_y_valid = false;
+  c->p2i8_y_valid = false;
   c->i8_guard = 0; c->i8_since_check = 0; c->i8_check_pending = false;      // new data: the int8 path is measured again (p1i8.hip, guard)
   return GP_OK;
 }

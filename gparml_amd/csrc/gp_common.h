@@ -97,6 +97,10 @@ struct gp_ctx {
   bool i8_active = false;     // this evaluation's phase 1 runs on the int8 matrix core (psi1_kernel wrote the digits)
   bool i8_y_valid = false;    // Y's digits are current (reset by gp_upload_shard)
   bool i8_unsupported = false;  // the int8 plan could not be built for this context (falls back to the float64 kernels)
+  void* p2i8plan = nullptr;     // int8 phase 2 (p2i8.hip): the column-contiguous digits of [K | Y], B's digits and scales; built on first use
+  bool p2i8_active = false;     // this evaluation: psi1_kernel wrote the second digit layout and phase 2 runs on the int8 matrix core
+  bool p2i8_y_valid = false;    // Y's digits in the second layout are current (reset by gp_upload_shard)
+  bool p2i8_unsupported = false;
   // the int8 path's run-time guard (p1i8.hip, "guard"): 0 = not checked since the last upload, 1 = accepted, 2 = rejected (float64 from then on)
   int i8_guard = 0;
   bool i8_check_pending = false;   // this evaluation ran both phase-1 paths: gp_finish reads the comparison and decides
@@ -220,6 +224,12 @@ int p1i8_check_begin(gp_ctx* c);      // after run_phase1_i8: keep the int8 stat
 int p1i8_check_compare(gp_ctx* c);    // after the float64 phase 1: norms of the difference (device)
 int p1i8_check_finish(gp_ctx* c);     // gp_finish, after the stream synchronisation of a checked evaluation: decide
 void p1i8_free(gp_ctx* c);
+// p2i8.hip (regime A phase 2 on the int8 matrix core; only together with the int8 phase 1)
+bool p2i8_wanted(const gp_ctx* c);
+int p2i8_prepare(gp_ctx* c, const double* yscale, int8_t** SlK, long* strideK, int* KS2);
+int run_phase2_i8(gp_ctx* c, const double* yscale, int* nparts);
+void p2i8_free(gp_ctx* c);
+const double* p1i8_yscale(const gp_ctx* c);     // Y's per-column digit scales (p1i8.hip plan)
 // p1v2.hip (regime A phase 1 without wasted tile slots)
 bool p1v2_applicable(const gp_ctx* c);
 int run_phase1_v2(gp_ctx* c);

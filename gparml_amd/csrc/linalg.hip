@@ -23,6 +23,7 @@ std::atomic<int> g_opt_dd_kipsi2{env_on("GPARML_DD_KIPSI2") ? 1 : 0};
 std::atomic<int> g_opt_refine_E{env_on("GPARML_REFINE_E") ? 1 : 0};
 extern std::atomic<int> g_opt_p1_i8;      // p1i8.hip
 extern std::atomic<int> g_opt_i8_guard_strict;
+extern std::atomic<int> g_opt_p2_i8;      // p2i8.hip
 
 constexpr int kSplitK = 8;   // split-k factor of the M x M x M products of the global step (latency-bound: 16 tiles alone fill 6 % of the chip)
 
@@ -677,8 +678,9 @@ extern "C" int gp_debug_set_option(const char* name, int value) {
   if (!std::strcmp(name, "refine_E")) { g_opt_refine_E.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "p1_i8")) { g_opt_p1_i8.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "gs_tail")) { g_opt_gs_tail.store(value ? 1 : 0); return GP_OK; }
+  if (!std::strcmp(name, "p2_i8")) { g_opt_p2_i8.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "i8_guard_strict")) { g_opt_i8_guard_strict.store(value ? 1 : 0); return GP_OK; }
-  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, gs_tail, i8_guard_strict)", name);
+  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, p2_i8, gs_tail, i8_guard_strict)", name);
 }
 
 extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet) {

@@ -383,6 +383,11 @@ int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ, double** Dpart, int row_
   return GP_OK;
 }
 
+const double* p1i8_yscale(const gp_ctx* c) {
+  const I8Plan* pl = static_cast<const I8Plan*>(c->i8plan);
+  return pl ? pl->yscale : nullptr;
+}
+
 int run_phase1_i8(gp_ctx* c) {
   I8Plan* pl = static_cast<I8Plan*>(c->i8plan);
   if (!pl || !pl->y_valid) return fail(c, GP_ERR_STATE, "int8 phase 1 without its digit buffers (psi1 did not write them)");

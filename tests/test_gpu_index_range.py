@@ -9,7 +9,7 @@ the one-shard context -- whose rows sit ABOVE the line -- than in the two half-s
 directional central finite difference of the bound against the analytic gradient.
 
   * fixed embeddings, N = 1.2e6, D = 1000, M = 1024, Q = 50: Kaug = 1 200 128 x 2048 = 2.46e9 doubles (19.7 GB);
-  * free embeddings, N = 2.2e6, D = 8, M = 1024: LE / LEA = 2 200 064 x 1024 = 2.25e9 doubles each, Kaug 2.53e9 -- at Q = 3 (phase 2 on
+  * free embeddings, N = 2.2e6, D = 8, M = 1024: LE / LEA = 2 200 064 x 1024 = 2.25e9 doubles each, Kaug 2.53e9 -- at Q = 6 (phase 2 on
     psi2_sym_kernel, phase 1 on psi2_pairs_kernel) and at Q = 20 (psi2_tile_kernel / psi2_pairs_mfma_kernel); the per-point partials
     HZp [8][Np][CZp] and pp follow the same row index.
 """
@@ -78,12 +78,14 @@ def _run(engines, emb):
     return out
 
 
-@pytest.mark.parametrize('N,D,M,Q,regime', [(1200000, 1000, 1024, 50, 'A'), (2200000, 8, 1024, 3, 'B'), (2200000, 8, 1024, 20, 'B')])
-def test_arrays_beyond_two_to_the_31_elements(N, D, M, Q, regime):
+@pytest.mark.parametrize('N,D,M,Q,regime,alpha', [(1200000, 1000, 1024, 50, 'A', None), (2200000, 8, 1024, 6, 'B', 0.8), (2200000, 8, 1024, 20, 'B', None)])
+def test_arrays_beyond_two_to_the_31_elements(N, D, M, Q, regime, alpha):
     emb = regime == 'B'
     Np, Mp, Dp = -(-N // 128) * 128, -(-M // 128) * 128, -(-D // 128) * 128
     assert Np * (Mp + Dp) > 2 ** 31 and (regime == 'A' or Np * Mp > 2 ** 31)          # the case is what its name says
     d = _generate(N, D, M, Q, regime, seed=50 + Q)
+    if alpha is not None:
+        d['alpha'] = np.full(Q, alpha)          # 1024 inducing points in a six-dimensional latent space: a shorter length scale keeps K_mm factorisable
     blocks = ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta') + (('grad_X_mu', 'grad_X_S') if emb else ())
     one = _engines(d, [0, N], N, D, M, Q)
     ref = _run(one, emb)

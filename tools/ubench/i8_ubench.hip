@@ -150,6 +150,33 @@ int main(int argc, char** argv) {
     printf("v_mfma_i32_32x32x32_i8, %d wave(s) per SIMD, 4 accumulators: %.0f TOPS (%.1f cycles per instruction per SIMD at 2.4 GHz)\n", wps, ops / ms / 1e9,
            ms * 1e-3 * 2.4e9 / (4.0 * iters * wps));
   }
+  // (2b) r05: the issue rate as a function of the distance between two MFMAs on the SAME accumulator (NACC accumulators round robin: distance NACC).
+  // The int8 phase 2 (csrc/p2i8.hip) adds seven digit products into its highest-order accumulator per k-step: how far apart must they be?
+  {
+    auto run = [&](auto kern, int nacc, int wps) {
+      const int iters = 20000, blocks = 256 * wps;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, 100, dout);
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, iters, dout);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("v_mfma_i32_32x32x32_i8, %d wave(s) per SIMD, same-accumulator distance %d: %.1f cycles per instruction per SIMD at 2.4 GHz\n", wps, nacc,
+             ms * 1e-3 * 2.4e9 / ((double)nacc * iters * wps));
+    };
+    // sustained: the same kernel for ~2, 10 and 50 ms -- does the rate hold (power / clock management)?
+    for (int iters : {40000, 200000, 1000000}) {
+      hipLaunchKernelGGL(rate32_kernel<7>, dim3(512), dim3(256), 0, 0, 100, dout);
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(rate32_kernel<7>, dim3(512), dim3(256), 0, 0, iters, dout);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("v_mfma_i32_32x32x32_i8 sustained, 2 waves per SIMD, 7 accumulators, %.1f ms: %.0f TOPS (%.1f cycles per instruction per SIMD at 2.4 GHz)\n", ms,
+             2.0 * 32 * 32 * 32 * 7.0 * iters * 512 * 4 / ms / 1e9, ms * 1e-3 * 2.4e9 / (7.0 * iters * 2));
+    }
+    for (int wps = 1; wps <= 2; ++wps) {
+      run(rate32_kernel<1>, 1, wps); run(rate32_kernel<2>, 2, wps); run(rate32_kernel<3>, 3, wps); run(rate32_kernel<4>, 4, wps); run(rate32_kernel<7>, 7, wps);
+    }
+  }
   // (3)
   const long rows = 1 << 20; const int cols = 512;
   double* dX; hipMalloc(&dX, rows * cols * 8);

@@ -326,9 +326,11 @@ def main():
     if os.environ.get('GPARML_BENCH_ONE_DEVICE'):
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    own_group = False
+    if world > 1 and not dist.is_initialized():        # (tests/test_gpu_bench_ranks.py calls main() inside a process that already has its group)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(os.environ.get('GPARML_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
+        own_group = True
     dev = torch.device('cuda', local_rank)
 
     from gparml_amd.engine import ShardEngine
@@ -486,7 +488,7 @@ def main():
                             regime_b_extra('BASELINE configs[4] at its FULL per-GPU size: N=1e6, D=1000, M=1024, Q=50, free embeddings', 1000000, 1000, 1024, 50,
                                            local_rank, steps=1, threaded=True)]
         print(json.dumps(res))
-    if world > 1:
+    if own_group:
         dist.destroy_process_group()
     eng.close()
 

@@ -17,11 +17,13 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 BENCH_TAIL = r"""
-# bench.py --gpus <world> end to end in the same processes (its own init_process_group / destroy_process_group)
+# bench.py --gpus <world> end to end in the same processes, on the process group the checks above used (a second init_process_group in the same
+# processes hung at eight ranks in round 5)
 os.environ['GPARML_BENCH_ONE_DEVICE'] = '1'; os.environ['GPARML_BENCH_BACKEND'] = 'gloo'
 import bench
 sys.argv = ['bench.py', '--gpus', str(world), '--steps', '3', '--warmup', '1'] + %(bench_shape)r
 bench.main()
+dist.destroy_process_group()
 print('RANK_OK', rank)
 """
 
@@ -197,7 +199,6 @@ for fname, optimiser, iters in (('pipe_gplvm_2shards.npz', 'scg', 2), ('gdpipe_g
         model.likelihood_and_gradient(x_opt, 'f')
         assert model.n_collectives - n1 == 2            # one evaluation = the two packed buffer all-reduces
     model.close()
-dist.destroy_process_group()
 """
 
 
@@ -207,7 +208,7 @@ def test_two_ranks_on_one_device(tmp_path):
     reference's 2-shard SCG and GD runs are reproduced call by call with one shard per process -- statistics / gradient all-reduces on
     the device buffers plus the optimisers' scalar sum / max reductions (scg_adapted_local_MapReduce.py:59-155); (3) bench.py --gpus 2."""
     text = (RANK_SCRIPT + SCG_RANK_SCRIPT) % {'root': ROOT} + BENCH_TAIL % {'bench_shape': ['--N', '30000', '--D', '12', '--M', '96', '--Q', '5']}
-    _launch(tmp_path, 'two_rank_script.py', text, 2, 1200)
+    _launch(tmp_path, 'two_rank_script.py', text, 2, 600)
 
 
 EIGHT_RANK_SCRIPT = r"""
@@ -280,7 +281,6 @@ alls = [None] * world
 dist.all_gather_object(alls, (f, vals))
 assert all(abs(o[0] - alls[0][0]) == 0 and np.array_equal(o[1], alls[0][1]) for o in alls)
 model.close()
-dist.destroy_process_group()
 """
 
 
@@ -290,4 +290,4 @@ def test_eight_ranks_on_one_device(tmp_path):
     dropped ranks, the jitter retry taken by all ranks together, the resident optimiser reductions, and bench.py --gpus 8 end to end
     with its all-reduce timings."""
     text = EIGHT_RANK_SCRIPT % {'root': ROOT} + BENCH_TAIL % {'bench_shape': ['--N', '20000', '--D', '12', '--M', '96', '--Q', '5']}
-    _launch(tmp_path, 'eight_rank_script.py', text, 8, 1500)
+    _launch(tmp_path, 'eight_rank_script.py', text, 8, 600)

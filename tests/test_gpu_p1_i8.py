@@ -197,7 +197,8 @@ def test_int8_phase2_against_the_float64_path_and_the_long_double_truth():
     finally:
         lib.gp_debug_set_option(b'p1_i8', 0); lib.gp_debug_set_option(b'p2_i8', 0)
         eng.close()
-    assert out['F'] == p1['F'] == again['F']                          # the bound does not depend on phase 2
+    assert out['F'] == again['F']
+    assert_close(out['F'], p1['F'], 1e-9, what='F')                   # phase 2 does not enter the bound; the two psi1_kernel forms extract phase 1's digits differently
     assert not np.array_equal(out['grad_Z'], p1['grad_Z'])            # a different phase-2 kernel did run
     assert np.array_equal(out['grad_Z'], again['grad_Z']) and np.array_equal(out['grad_alpha'], again['grad_alpha'])
     for k in keys:

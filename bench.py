@@ -128,29 +128,48 @@ def extended_precision_cost(eng, d, N, D, M, Q, seed):
     return res
 
 
-def int8_phase1_variant(eng, d, N, D, M, Q, seed, steps=10):
-    """The same workload with phase 1 on the int8 matrix core (csrc/p1i8.hip, opt-in: exact integer products of six 7-bit digits per operand, 21 digit
-    products, Psi2's diagonal from float64 sums of squares): device ms per evaluation next to the float64 default of the same run, and
-    the distance of ITS gradients from the extended-precision truth.  Timed outside the headline region."""
+INT8_PEAK_TOPS = 4880.0    # v_mfma_i32_32x32x32_i8, sustained for 190 ms on this part (tools/ubench/i8_ubench.hip, profiles/r05_int8_phase2.txt)
+
+
+def int8_variants(eng, d, N, D, M, Q, seed, steps=10):
+    """The same workload on the opt-in int8 paths, timed OUTSIDE the headline region and priced against the int8 matrix core's own peak (the headline
+    stays on the float64 matrix core): phase 1 (csrc/p1i8.hip: six signed 7-bit digits per operand, 21 exact digit products, Psi2's diagonal from float64
+    sums of squares, guarded at run time -- gp_i8_status) and, experimental, phase 2 as well (csrc/p2i8.hip: seven digits, 28 products; correct, not
+    faster: profiles/r05_int8_phase2.txt).  Device ms per evaluation next to the float64 default of the same run and the distance of each variant's
+    gradients from the extended-precision truth."""
     from gparml_amd import _lib
     lib = _lib.load()
     res = {}
     try:
-        for name, on in (('float64 (default, p1v2_kernel)', 0), ('int8 (p1i8_kernel)', 1)):
-            lib.gp_debug_set_option(b'p1_i8', on)
+        for name, p1, p2 in (('float64 (default: p1v2_kernel, p2_fast8_kernel)', 0, 0), ('int8 phase 1 (p1i8_kernel)', 1, 0),
+                             ('int8 phases 1 + 2 (p1i8_kernel, p2i8_kernel; experimental)', 1, 1)):
+            lib.gp_debug_set_option(b'p1_i8', p1)
+            lib.gp_debug_set_option(b'p2_i8', p2)
             eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
             tot = {}
-            for i in range(steps + 2):
+            for i in range(steps + 3):            # the first int8 evaluation is the guard's check (both phase-1 paths): not in the average
                 out = eng.evaluate(False)
-                if i >= 2:
+                if i >= 3:
                     for k, v in eng.timings().items():
                         tot[k] = tot.get(k, 0.0) + v / steps
             te = truth_errors(d, out, N, D, M, Q, seed)
-            res[name] = {'ms_per_eval_device': round(tot['total_ms'], 4), 'psi1_ms': round(tot['psi1_ms'], 4), 'p1_kernel_ms': round(tot['p1_kernel_ms'], 4),
-                         'p2_kernel_ms': round(tot['p2_kernel_ms'], 4), 'grad_Z_err_vs_truth': None if te is None else te['grad_Z_err_vs_truth'],
-                         'F_err_vs_truth': None if te is None else te['F_err_vs_truth']}
+            r = {'ms_per_eval_device': round(tot['total_ms'], 4), 'psi1_ms': round(tot['psi1_ms'], 4), 'p1_kernel_ms': round(tot['p1_kernel_ms'], 4),
+                 'p2_kernel_ms': round(tot['p2_kernel_ms'], 4), 'global_ms': round(tot['global_ms'], 4),
+                 'grad_Z_err_vs_truth': None if te is None else te['grad_Z_err_vs_truth'], 'F_err_vs_truth': None if te is None else te['F_err_vs_truth']}
+            if p1:
+                # 21 digit products of (N M^2 / 2 + N M D) multiply-adds each on the int8 matrix core
+                ops = 2.0 * 21.0 * (0.5 * N * M * M + float(N) * M * D)
+                ach = ops / (tot['p1_kernel_ms'] * 1e-3) / 1e12
+                r['roofline'] = {'bound': 'mfma', 'kernel': 'gp::p1i8_kernel', 'achieved': ach, 'peak': INT8_PEAK_TOPS, 'unit': 'TOP/s (int8)', 'frac': ach / INT8_PEAK_TOPS}
+                r['guard'] = eng.i8_status()
+            if p2:
+                ops2 = 2.0 * 28.0 * float(N) * M * (M + D)
+                ach2 = ops2 / (tot['p2_kernel_ms'] * 1e-3) / 1e12
+                r['roofline_phase2'] = {'bound': 'mfma', 'kernel': 'gp::p2i8_kernel', 'achieved': ach2, 'peak': INT8_PEAK_TOPS, 'unit': 'TOP/s (int8)', 'frac': ach2 / INT8_PEAK_TOPS}
+            res[name] = r
     finally:
         lib.gp_debug_set_option(b'p1_i8', 0)
+        lib.gp_debug_set_option(b'p2_i8', 0)
     return res
 
 
@@ -467,7 +486,7 @@ def main():
             # with grad_Z's distance from the truth for each setting
             res['config']['extended_precision_cost'] = extended_precision_cost(eng, d, N, D, M, Q, 100 + rank)
             if not a.no_extra and (N, D, M, Q) == (1000000, 100, 512, 10):
-                res['config']['phase1_int8_variant'] = int8_phase1_variant(eng, d, N, D, M, Q, 100 + rank)
+                res['config']['int8_variant'] = int8_variants(eng, d, N, D, M, Q, 100 + rank)
         if a.regime == 'A':
             # parity of THIS run's last evaluation against the extended-precision truth of the same workload (rank 0's shard alone:
             # only meaningful for one shard), and the conditioning it was obtained at

@@ -22,8 +22,10 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
   const double* B = p.B + (long)bi * p.sB + (long)bo * p.oB;
   double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
   const long row0 = (long)by * TILE, col0 = (long)bx * TILE;
-  const int nc = p.K / KC / p.splits;          // chunks of this split
-  const long k0 = (long)sp * nc * KC;
+  // klow (X^T X, X lower-triangular): the tile's k-range starts at its first possibly non-zero k, a multiple of 128; the splits share what is left
+  const long klo = p.klow ? (row0 > col0 ? row0 : col0) : 0;
+  const int nc = (int)((p.K - klo) / KC / p.splits);          // chunks of this split
+  const long k0 = klo + (long)sp * nc * KC;
   const double* Ab = (LA == K_CONTIG) ? A + row0 * p.lda + k0 : A + row0 + k0 * p.lda;
   const double* Bb = (LB == K_CONTIG) ? B + col0 * p.ldb + k0 : B + col0 + k0 * p.ldb;
   const long a_step = (LA == K_CONTIG) ? KC : (long)KC * p.lda;
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmP p) {
       for (int bc = 0; bc < 16; ++bc) {
         const long r = row0 + wrow0 + acc_row(ar, lane), cc = col0 + wcol0 + acc_col(bc, lane);
         C[r * p.ldc + cc] = p.alpha * acc.v[ar][bc];
+        if (p.mirror && bx != by) C[cc * p.ldc + r] = p.alpha * acc.v[ar][bc];
       }
   }
 }
@@ -85,7 +88,10 @@ __global__ void __launch_bounds__(256, 1) gemm32_kernel(GemmP p) {
 }
 
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int tiles_x, int tiles_y) {
-  // grid (tiles * 16, batch): 16 blocks of 256 threads per 128x128 tile, 4 elements each
+  // grid (tiles * 16, batch): 16 blocks of 256 threads per 128x128 tile, one 32 x 32 sub-block each (four elements per thread, rows of 32 doubles);
+  // the mirrored copy of an off-diagonal tile (GemmP::mirror) goes through an LDS transposition so that it, too, is written in 256-byte runs
+  // (as scattered 8-byte stores the reduce of X^T X took 29 us at M = 1024 against 15 us for the other products)
+  __shared__ double tr[32][33];
   const int tile = blockIdx.x >> 4, sub = blockIdx.x & 15;
   const int bx = tile % tiles_x, by = tile / tiles_x, bz = blockIdx.y;
   if (p.tri == 1 && bx > by) return;
@@ -93,19 +99,32 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int ti
   const int bi = bz % p.inner, bo = bz / p.inner;
   double* C = p.C + (long)bi * p.sC + (long)bo * p.oC;
   const double* w = p.ws + (((long)bz * tiles_y + by) * tiles_x + bx) * p.splits * (TILE * TILE);
+  const int sr = 32 * (sub >> 2), sc = 32 * (sub & 3), lc = threadIdx.x & 31, lr0 = threadIdx.x >> 5;
+  const bool mir = p.mirror && bx != by;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int e = sub * 1024 + i * 256 + threadIdx.x;
+    const int lr = 8 * i + lr0;
+    const int e = (sr + lr) * TILE + sc + lc;
     double s = 0.0;
     for (int sp = 0; sp < p.splits; ++sp) s += w[(long)sp * (TILE * TILE) + e];
-    const long r = (long)by * TILE + (e >> 7), cc = (long)bx * TILE + (e & 127);
-    C[r * p.ldc + cc] = p.alpha * s + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
+    const long r = (long)by * TILE + sr + lr, cc = (long)bx * TILE + sc + lc;
+    const double v = p.alpha * s + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
+    C[r * p.ldc + cc] = v;
+    if (mir) tr[lr][lc] = v;
+  }
+  if (mir) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = 8 * i + lr0;      // row of the transposed sub-block = column of the original
+      C[((long)bx * TILE + sc + lr) * p.ldc + (long)by * TILE + sr + lc] = tr[lc][lr];
+    }
   }
 }
 
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p) {
   dim3 grid(n / TILE, m / TILE, batch * p.splits), block(256);
-  if ((long)(n / TILE) * (m / TILE) * batch <= 256) {
+  if (!p.big && (long)(n / TILE) * (m / TILE) * batch <= 256) {
     // few tiles (the global step): 32 x 32 tiles spread the product over the chip; split-k is not needed there
     dim3 g32(n / ST, m / ST, batch);
     if (la == K_CONTIG && lb == FREE_CONTIG) hipLaunchKernelGGL((gemm32_kernel<K_CONTIG, FREE_CONTIG>), g32, block, 0, st, p);

@@ -65,6 +65,7 @@ __device__ __forceinline__ void gemm32_tile(const GemmP& p, int bx, int by, int 
   const long a_step = (LA == K_CONTIG) ? SKC : (long)SKC * p.lda;
   const long b_step = (LB == K_CONTIG) ? SKC : (long)SKC * p.ldb;
   const int nc = (p.K + SKC - 1) / SKC;
+  const int c0 = p.klow ? (int)((row0 > col0 ? row0 : col0) / SKC) : 0;     // first chunk with a possibly non-zero product
   // NOT zeroed in C++: hipcc rematerialises such zeros as v_mov_b64 right in front of the first asm MFMA of each accumulator, and in the fused
   // tail kernel it put one of them on a register the previous MFMA was still reading as its B operand (columns 4..7 of every tile wrong, r05).
   // The first k-step of the first chunk takes C = 0 as an inline constant instead (mfma444_zero).
@@ -72,9 +73,9 @@ __device__ __forceinline__ void gemm32_tile(const GemmP& p, int bx, int by, int 
   const unsigned aA = lds_byte_addr(sA) + 8u * (unsigned)(LA == K_CONTIG ? (wr + lr) * LDA + lk : lk * LDA + wr + lr);
   const unsigned aB = lds_byte_addr(sB) + 8u * (unsigned)(LB == K_CONTIG ? (wc + lj) * LDB + lk : lk * LDB + wc + lj);
   double2 ra[8], rb[8];
-  small_load<LA>(Ab, p.lda, p.K, tid, ra);
-  small_load<LB>(Bb, p.ldb, p.K, tid, rb);
-  for (int c = 0; c < nc; ++c) {
+  small_load<LA>(Ab + (long)c0 * a_step, p.lda, p.K - c0 * SKC, tid, ra);
+  small_load<LB>(Bb + (long)c0 * b_step, p.ldb, p.K - c0 * SKC, tid, rb);
+  for (int c = c0; c < nc; ++c) {
     small_store<LA>(sA, tid, ra);
     small_store<LB>(sB, tid, rb);
     __syncthreads();
@@ -96,7 +97,7 @@ __device__ __forceinline__ void gemm32_tile(const GemmP& p, int bx, int by, int 
       constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
       if constexpr (k4 + 1 < SKC / 4) { rd(IC<k4 + 1>{}, a[cur ^ 1], b[cur ^ 1]); lgkm_wait<5>(); }
       else lgkm_wait<0>();
-      if (k4 == 0 && c == 0) {
+      if (k4 == 0 && c == c0) {
 #pragma unroll
         for (int bc = 0; bc < 4; ++bc) mfma444_zero(acc[bc], a[cur], b[cur][bc]);
       } else {
@@ -112,7 +113,9 @@ __device__ __forceinline__ void gemm32_tile(const GemmP& p, int bx, int by, int 
 #pragma unroll
   for (int bc = 0; bc < 4; ++bc) {
     const long cc = col0 + wc + 4 * bc + lj;
-    C[r * p.ldc + cc] = p.alpha * acc[bc] + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
+    const double v = p.alpha * acc[bc] + (p.beta != 0.0 ? p.beta * C[r * p.ldc + cc] : 0.0);
+    C[r * p.ldc + cc] = v;
+    if (p.mirror && bx != by) C[cc * p.ldc + r] = v;
   }
 }
 

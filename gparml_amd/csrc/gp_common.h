@@ -34,6 +34,12 @@ struct GemmP {
   long oA = 0, oB = 0, oC = 0;
   int splits = 1;       // split-k: partial tiles go to ws, gemm_splitk_reduce applies alpha/beta (small grids only)
   double* ws = nullptr;
+  // X^T X with X lower-triangular (both operands FREE_CONTIG, stored [k][free], zero for k < free): with tri = 1 only the tiles on or below the diagonal
+  // are computed, klow = 1 starts their k-range at the tile's first possibly non-zero k = max(row0, col0) (the skipped products are exact zeros:
+  // same bits), mirror = 1 stores every off-diagonal tile a second time transposed (the two halves were equal bit for bit before: same k order, and a
+  // product does not depend on which factor is the A operand)
+  int klow = 0, mirror = 0;
+  int big = 0;          // 1: the 128 x 128-tile kernel (with splits) whatever the tile count (the M x M x M products at M >= 1024)
 };
 // m, n multiples of TILE; la/lb: Layout of A (free index = rows of C) and B (free index = cols of C)
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p);
@@ -80,6 +86,7 @@ struct gp_ctx {
   double* Z = nullptr;        // [Mp][Q] (rows >= M zero)
   double* alpha = nullptr;    // [Q]
   double* Zaug = nullptr;     // [Mp][CZp]
+  double* Zt = nullptr;       // [Q][Mp] the inducing points transposed (kmm_grads_kernel: lanes = inducing points)
   double* stats = nullptr;    // packed: Psi2 [Mp*Mp] | C [Mp*Dp] | scalars [SC_COUNT]
   bool stats_external = false;
   double* spack = nullptr;    // Psi2 upper triangle | C [M][D] | scalars: the all-reduce payload across processes (allocated on first use)

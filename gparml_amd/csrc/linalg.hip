@@ -25,11 +25,17 @@ extern std::atomic<int> g_opt_p1_i8;      // p1i8.hip
 extern std::atomic<int> g_opt_i8_guard_strict;
 extern std::atomic<int> g_opt_p2_i8;      // p2i8.hip
 
+// r05, the global step at M >= 1024 (each switchable for same-box A/B through gp_debug_set_option):
+std::atomic<int> g_opt_xtx_tri{1};       // A^-1 = X^T X from its lower tiles, k from the tile's first non-zero row, mirrored store (bit-identical)
+std::atomic<int> g_opt_residual_dd{1};   // the refinement residual through ddacc_block (two rows per wave share E's loads) for Mp >= 256
+std::atomic<int> g_opt_trtri_rec{1};     // L^-1 by halves: two batched launches per level instead of two per block row
+std::atomic<int> g_opt_gemm_big{1};      // the M x M x {M, D} products on the 128 x 128-tile kernel (split-k 8 at M = 1024) for Mp >= 1024
+
 constexpr int kSplitK = 8;   // split-k factor of the M x M x M products of the global step (latency-bound: 16 tiles alone fill 6 % of the chip)
 
 
 
-// A: [batch][Mp][Mp] SPD in, lower Cholesky factor out (upper zeroed); Linv: L^-1; Inv: A^-1; Twork: [batch][128][Mp]
+// A: [batch][Mp][Mp] SPD in, lower Cholesky factor out (upper zeroed); Linv: L^-1; Inv: A^-1; Twork: batch * Mp * Mp / 2 doubles
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A, double* Linv, double* Inv, double* Twork,
                           double* logdet2, double* fail_flag, double* splitk_ws) {
   const int nt = Mp / NB;
@@ -57,20 +63,49 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
       launch_gemm(st, K_CONTIG, K_CONTIG, rem * NB, rem * NB, batch, q);
     }
   }
-  // block rows of X = L^-1: X[i,0:i] = -X_ii * (L[i,0:i] * X[0:i,0:i])
-  for (int i = 1; i < nt; ++i) {
-    GemmP p;
-    p.A = A + ((long)i * NB) * ld; p.lda = ld; p.sA = bs;            // L row panel (128 x i*128), K_CONTIG
-    p.B = Linv; p.ldb = ld; p.sB = bs;                               // X[0:i,0:i] stored [k][c] -> FREE_CONTIG
-    p.C = Twork; p.ldc = Mp; p.sC = (long)NB * Mp;
-    p.K = i * NB; p.alpha = 1.0; p.beta = 0.0; p.tri = 0;
-    launch_gemm(st, K_CONTIG, FREE_CONTIG, NB, i * NB, batch, p);
-    GemmP q;
-    q.A = Linv + ((long)i * NB) * ld + (long)i * NB; q.lda = ld; q.sA = bs;   // X_ii, K_CONTIG
-    q.B = Twork; q.ldb = Mp; q.sB = (long)NB * Mp;                            // T stored [k][c] -> FREE_CONTIG
-    q.C = Linv + ((long)i * NB) * ld; q.ldc = ld; q.sC = bs;
-    q.K = NB; q.alpha = -1.0; q.beta = 0.0; q.tri = 0;
-    launch_gemm(st, K_CONTIG, FREE_CONTIG, NB, i * NB, batch, q);
+  if (g_opt_trtri_rec.load()) {
+    // X = L^-1 below the diagonal blocks by halves (r05): with L = [L11 0 ; L21 L22], X21 = -X22 (L21 X11).  Level h = 1, 2, 4, ... (half size in
+    // 128-blocks): every pair of halves of that size is independent of the others, so a level is TWO batched launches whatever M -- 2 log2(M / 128)
+    // launches with M / 256 ... 1 products each instead of 2 (M / 128 - 1) launches of one growing block row (M = 1024: 6 launches for 14, 115 us before).
+    // A pair whose second half runs past the matrix (block counts that are no power of two) is launched on its own with the shorter row count.
+    for (int h = 1; h < nt; h *= 2) {
+      const long b = (long)h * NB, ps = 2 * b * (ld + 1);
+      const int full = nt / (2 * h), rem = nt - full * 2 * h - h;
+      auto level = [&](int p0, int np, int rows2) {
+        const long o11 = ((long)(2 * p0 * h) * NB) * (ld + 1), o22 = o11 + b * (ld + 1), o21 = o11 + b * ld;
+        const long m2 = (long)rows2 * NB;
+        GemmP p;                                                        // T = L21 X11
+        p.A = A + o21; p.lda = ld; p.sA = ps; p.oA = bs;                // L21 [m][k], K_CONTIG
+        p.B = Linv + o11; p.ldb = ld; p.sB = ps; p.oB = bs;             // X11 stored [k][c], FREE_CONTIG
+        p.C = Twork; p.ldc = b; p.sC = m2 * b; p.oC = (long)np * m2 * b;
+        p.K = (int)b; p.alpha = 1.0; p.beta = 0.0; p.tri = 0; p.inner = np;
+        launch_gemm(st, K_CONTIG, FREE_CONTIG, (int)m2, (int)b, np * batch, p);
+        GemmP q;                                                        // X21 = -X22 T
+        q.A = Linv + o22; q.lda = ld; q.sA = ps; q.oA = bs;             // X22 [m][k], K_CONTIG
+        q.B = Twork; q.ldb = b; q.sB = m2 * b; q.oB = (long)np * m2 * b;
+        q.C = Linv + o21; q.ldc = ld; q.sC = ps; q.oC = bs;
+        q.K = (int)m2; q.alpha = -1.0; q.beta = 0.0; q.tri = 0; q.inner = np;
+        launch_gemm(st, K_CONTIG, FREE_CONTIG, (int)m2, (int)b, np * batch, q);
+      };
+      if (full > 0) level(0, full, h);
+      if (rem > 0) level(full, 1, rem);
+    }
+  } else {
+    // block rows of X = L^-1: X[i,0:i] = -X_ii * (L[i,0:i] * X[0:i,0:i])
+    for (int i = 1; i < nt; ++i) {
+      GemmP p;
+      p.A = A + ((long)i * NB) * ld; p.lda = ld; p.sA = bs;            // L row panel (128 x i*128), K_CONTIG
+      p.B = Linv; p.ldb = ld; p.sB = bs;                               // X[0:i,0:i] stored [k][c] -> FREE_CONTIG
+      p.C = Twork; p.ldc = Mp; p.sC = (long)NB * Mp;
+      p.K = i * NB; p.alpha = 1.0; p.beta = 0.0; p.tri = 0;
+      launch_gemm(st, K_CONTIG, FREE_CONTIG, NB, i * NB, batch, p);
+      GemmP q;
+      q.A = Linv + ((long)i * NB) * ld + (long)i * NB; q.lda = ld; q.sA = bs;   // X_ii, K_CONTIG
+      q.B = Twork; q.ldb = Mp; q.sB = (long)NB * Mp;                            // T stored [k][c] -> FREE_CONTIG
+      q.C = Linv + ((long)i * NB) * ld; q.ldc = ld; q.sC = bs;
+      q.K = NB; q.alpha = -1.0; q.beta = 0.0; q.tri = 0;
+      launch_gemm(st, K_CONTIG, FREE_CONTIG, NB, i * NB, batch, q);
+    }
   }
   // A^-1 = X^T X
   GemmP r;
@@ -78,7 +113,9 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
   r.B = Linv; r.ldb = ld; r.sB = bs;   // B(k,j) = X[k][j] -> FREE_CONTIG
   r.C = Inv; r.ldc = ld; r.sC = bs;
   r.K = Mp; r.alpha = 1.0; r.beta = 0.0; r.tri = 0;
+  if (g_opt_xtx_tri.load()) { r.tri = 1; r.klow = 1; r.mirror = 1; }
   if (splitk_ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0) { r.splits = kSplitK; r.ws = splitk_ws; }
+  r.big = (g_opt_gemm_big.load() && Mp >= 1024 && (r.splits > 1 || (long)(Mp / TILE) * (Mp / TILE) * batch >= 256)) ? 1 : 0;
   launch_gemm(st, FREE_CONTIG, FREE_CONTIG, Mp, Mp, batch, r);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -90,18 +127,39 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
 __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict__ Z, const double* __restrict__ alpha, double sf2,
                                                          double beta, const double* __restrict__ Psi2, int M, int Mp, int Q,
                                                          double* __restrict__ Kmm, double* __restrict__ A, double* __restrict__ Keep,
-                                                         double jitK, double jitA, double* __restrict__ gs_zero) {
-  const long total = (long)Mp * Mp;
+                                                         double jitK, double jitA, double* __restrict__ gs_zero, double* __restrict__ Acopy) {
+  // workgroup = 16 rows x 64 columns: the 64 columns' inducing points transposed into LDS ([q][column], conflict-free), the row's point wave-uniform
+  // (scalar loads); one element per lane and row.  (The first form read Z[k * Q + q] with a stride of Q doubles across the lanes: 37 us at M = 1024,
+  // Q = 50.)  The exponent is summed over q in the same order as before: same bits.
+  __shared__ double zs[64 * 65];
+  __shared__ double as[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k0 = blockIdx.x * 64, i0 = blockIdx.y * 16;
   // the global step's device scalars and failure flags start from zero (this used to be a hipMemsetAsync: a blit dispatch with ~10 us of idle
   // stream around it); the panel kernels that write them are later launches
-  if (blockIdx.x == 0 && threadIdx.x < GS_COUNT + 8) gs_zero[threadIdx.x] = 0.0;
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-    const int i = (int)(idx / Mp), k = (int)(idx - (long)i * Mp);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < GS_COUNT + 8) gs_zero[tid] = 0.0;
+  const int Qs = Q < 64 ? Q : 64;                     // latent dimensions beyond 64 are read from global memory
+  for (int e = tid; e < 64 * Qs; e += 256) {
+    const int kk = e / Qs, q = e - kk * Qs;
+    zs[q * 65 + kk] = (k0 + kk < M) ? Z[(long)(k0 + kk) * Q + q] : 0.0;
+  }
+  if (tid < Qs) as[tid] = alpha[tid];
+  __syncthreads();
+  const int k = k0 + lane;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int i = i0 + 4 * wave + rr;
+    const long idx = (long)i * Mp + k;
     double v;
     if (i < M && k < M) {
+      const double* zi = Z + (long)i * Q;
       double e = 0.0;
-      for (int q = 0; q < Q; ++q) {
-        const double d = Z[(long)i * Q + q] - Z[(long)k * Q + q];
+      for (int q = 0; q < Qs; ++q) {
+        const double d = zi[q] - zs[q * 65 + lane];
+        e = fma(as[q] * d, d, e);
+      }
+      for (int q = Qs; q < Q; ++q) {
+        const double d = zi[q] - Z[(long)k * Q + q];
         e = fma(alpha[q] * d, d, e);
       }
       v = sf2 * exp(-0.5 * e);
@@ -111,7 +169,9 @@ __global__ void __launch_bounds__(256) build_kmm_kernel(const double* __restrict
     const bool diag = (i == k) && i < M;
     Kmm[idx] = v + (diag ? jitK : 0.0);
     Keep[idx] = v;
-    A[idx] = ((i < M && k < M) ? fma(beta, Psi2[idx], v) : v) + (diag ? jitA : 0.0);   // the same expression as in solve_residual_kernel
+    const double a = ((i < M && k < M) ? fma(beta, Psi2[idx], v) : v) + (diag ? jitA : 0.0);   // the same expression as in solve_residual_kernel
+    A[idx] = a;
+    if (Acopy) Acopy[idx] = a;                          // the factorisation overwrites A; the double-double residual reads this copy
   }
 }
 
@@ -203,9 +263,10 @@ __device__ __forceinline__ void residual_row256(int m, const double* __restrict_
 // (the same arithmetic emulated with numpy error-free transformations before it was built).  No extended-precision inverse,
 // no Newton step, no double-double storage is needed.  1024 waves at M = 512 with RB = 4; the four waves of a workgroup share their column
 // block, so B's rows are read from L2 once per workgroup.
-template <int RB, int KU>
+// SUB: the residual of the refinement step, C = (Csub - hi) - lo (solve_residual_kernel's rounding), instead of C = hi + lo.
+template <int RB, int KU, bool SUB = false>
 __device__ __forceinline__ void ddacc_block(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int K,
-                                            double* __restrict__ C, long ldc, int vbx, int vby) {
+                                            double* __restrict__ C, long ldc, int vbx, int vby, const double* __restrict__ Csub = nullptr) {
 #pragma clang fp contract(off)   // hi + a b as one FMA would break the two-sum
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = vbx * 64 + lane;
@@ -232,12 +293,23 @@ __device__ __forceinline__ void ddacc_block(const double* __restrict__ A, long l
     }
   }
 #pragma unroll
-  for (int r = 0; r < RB; ++r) C[(long)(i0 + r) * ldc + j] = hi[r] + lo[r];
+  for (int r = 0; r < RB; ++r) {
+    if constexpr (SUB) C[(long)(i0 + r) * ldc + j] = (Csub[(long)(i0 + r) * ldc + j] - hi[r]) - lo[r];
+    else C[(long)(i0 + r) * ldc + j] = hi[r] + lo[r];
+  }
 }
 template <int RB, int KU>
 __global__ void __launch_bounds__(256) ddacc_gemm_kernel(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int K,
                                                           double* __restrict__ C, long ldc) {
   ddacc_block<RB, KU>(A, lda, B, ldb, K, C, ldc, blockIdx.x, blockIdx.y);
+}
+// R = C - A E with the sum in double-double: the refinement residual for Mp >= 256 (solve_residual_kernel: one row per workgroup, every lane its own
+// load of E per product and two extra instructions to rebuild A[m][k]; 570 us at M = 1024, D = 1000 against the 356 us of the equally large
+// product above).  A is the copy build_kmm_kernel keeps, padded rows and columns included: R's padding comes out as exact zeros.
+template <int RB, int KU>
+__global__ void __launch_bounds__(256) ddacc_residual_kernel(const double* __restrict__ A, long lda, const double* __restrict__ E, long lde, int K,
+                                                              const double* __restrict__ Csub, double* __restrict__ R) {
+  ddacc_block<RB, KU, true>(A, lda, E, lde, K, R, lde, blockIdx.x, blockIdx.y, Csub);
 }
 
 // sum over the M x M (or M x D) block of x o y; one block per pair, results into out[slot]
@@ -327,16 +399,68 @@ constexpr int KG_QC = 8;
 __device__ __forceinline__ void kmm_grads_row(int j, bool active, int tid, double* red, const double* __restrict__ dFdK, const double* __restrict__ Kmm,
                                               const double* __restrict__ Bbar, const double* __restrict__ Psi2, const double* __restrict__ Z,
                                               const double* __restrict__ alpha, int M, int Mp, int Q, int regimeA, double* __restrict__ gZ,
-                                              double* __restrict__ gapart) {
+                                              double* __restrict__ gapart, double* symw = nullptr, const double* __restrict__ Zt = nullptr) {
   // latent dimensions in chunks of 8: the sums of a chunk stay in registers over the row, then one butterfly per sum and one
   // LDS hand-over between the two waves (the first version ran two 7-step workgroup reductions per latent dimension)
   constexpr int QC = KG_QC;
   const int lane = tid & 63, wave = tid >> 6;
+  // what does not depend on q, once per row: sym = (dF/dK + dF/dK^T)[j][m] K[j][m] and the alpha weight w (the column read dF/dK[m][j] is one cache
+  // line per element: at Q = 50 the loop below used to fetch it seven times -- 61 us per 1024 rows).  symw: 2 * 128 * ceil(M / 128) doubles of LDS,
+  // [t][tid] and [nm + t][tid]: every thread reads back only what it wrote (no barrier); nullptr: recomputed per chunk as before (the fused tail).
+  const bool inlds = symw != nullptr;
+  const int nm = (M + 127) / 128;
+  if (inlds && active) {
+    // four inducing points per trip with clamped addresses and zero weights for the ones past M: no branch around the loads, so all of a trip's loads
+    // are in flight together (one row was 64 dependent load round trips: 86 us per launch whatever the layout of Z)
+    for (int t0 = 0; t0 < nm; t0 += 4) {
+      double k[4], fjm[4], fmj[4], bb[4], pp[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int m = min(tid + 128 * (t0 + tt), M - 1);
+        k[tt] = Kmm[(long)j * Mp + m];
+        fjm[tt] = dFdK[(long)j * Mp + m];
+        fmj[tt] = dFdK[(long)m * Mp + j];
+        if (!regimeA) { bb[tt] = Bbar[(long)j * Mp + m]; pp[tt] = Psi2[(long)j * Mp + m]; }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int t = t0 + tt;
+        if (t < nm) {
+          const bool ok = tid + 128 * t < M;
+          const double sym = (fjm[tt] + fmj[tt]) * k[tt];
+          double w = -0.5 * fjm[tt] * k[tt];
+          if (!regimeA) w += -0.25 * bb[tt] * pp[tt];
+          symw[t * 128 + tid] = ok ? sym : 0.0; symw[(nm + t) * 128 + tid] = ok ? w : 0.0;
+        }
+      }
+    }
+  }
   for (int q0 = 0; q0 < Q; q0 += QC) {
     double sz[QC], sa[QC], zj[QC];
 #pragma unroll
     for (int u = 0; u < QC; ++u) { sz[u] = 0.0; sa[u] = 0.0; zj[u] = (active && q0 + u < Q) ? Z[(long)j * Q + q0 + u] : 0.0; }
-    if (active)
+    if (active && inlds) {
+      for (int t0 = 0; t0 < nm; t0 += 4) {
+        double zz[4][QC], sy[4], ww[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int t = t0 + tt, tc = t < nm ? t : nm - 1;
+          const int m = min(tid + 128 * tc, M - 1);
+          sy[tt] = t < nm ? symw[tc * 128 + tid] : 0.0;          // zero for an inducing point past M (and for the trip's unused slots):
+          ww[tt] = t < nm ? symw[(nm + tc) * 128 + tid] : 0.0;   // fma(0, dz, s) = s exactly, the sums are those of the loop over m < M
+#pragma unroll
+          for (int u = 0; u < QC; ++u) zz[tt][u] = (q0 + u < Q) ? Zt[(long)(q0 + u) * Mp + m] : 0.0;   // lanes = consecutive inducing points
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int u = 0; u < QC; ++u) {
+            const double dz = zj[u] - zz[tt][u];
+            sz[u] = fma(sy[tt], dz, sz[u]);
+            sa[u] = fma(ww[tt] * dz, dz, sa[u]);
+          }
+      }
+    } else if (active)
       for (int m = tid; m < M; m += 128) {
         const double k = Kmm[(long)j * Mp + m];
         const double fjm = dFdK[(long)j * Mp + m];
@@ -375,9 +499,11 @@ __device__ __forceinline__ void kmm_grads_row(int j, bool active, int tid, doubl
 __global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict__ dFdK, const double* __restrict__ Kmm,
                                                          const double* __restrict__ Bbar, const double* __restrict__ Psi2,
                                                          const double* __restrict__ Z, const double* __restrict__ alpha, int M, int Mp,
-                                                         int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart) {
+                                                         int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart, int lds_weights,
+                                                         const double* __restrict__ Zt) {
   __shared__ double red[2 * KG_QC];
-  kmm_grads_row(blockIdx.x, true, threadIdx.x, red, dFdK, Kmm, Bbar, Psi2, Z, alpha, M, Mp, Q, regimeA, gZ, gapart);
+  extern __shared__ __attribute__((aligned(16))) double symw_lds[];      // 2 * 128 * ceil(M / 128) doubles when Q needs more than one chunk, else none
+  kmm_grads_row(blockIdx.x, true, threadIdx.x, red, dFdK, Kmm, Bbar, Psi2, Z, alpha, M, Mp, Q, regimeA, gZ, gapart, lds_weights ? symw_lds : nullptr, lds_weights ? Zt : nullptr);
 }
 // column q of part [rows][Q] summed by the calling 256-thread workgroup; red: 256 doubles of LDS
 __device__ __forceinline__ void colsum_block(const double* __restrict__ part, int rows, int Q, double* __restrict__ out, int q, double* red) {
@@ -553,8 +679,10 @@ int run_global_step(gp_ctx* c) {
   double* sc = c->stats + mm + (long)Mp * Dp;
   c->gs_status = GP_OK;
   double* failf = c->gs + GS_COUNT;  // [2]
-  hipLaunchKernelGGL(build_kmm_kernel, dim3(1024), dim3(256), 0, st, c->Z, c->alpha, c->sf2, c->beta, Psi2, M, Mp, Q, c->Kmm, c->Kmm + mm,
-                     c->KmmKeep, (c->jitter_mask & 1) ? 1e-7 : 0.0, (c->jitter_mask & 2) ? 1e-7 : 0.0, c->gs);
+  // T2 is free until G = K_mm^-1 Psi2 is formed: it keeps A for the double-double residual of the refinement step
+  const bool res_dd = g_opt_refine_E.load() && g_opt_residual_dd.load() && Mp >= 256 && Dp >= 512;   // narrow E: too few waves (M = 512, D = 100: +21 us)
+  hipLaunchKernelGGL(build_kmm_kernel, dim3(Mp / 64, Mp / 16), dim3(256), 0, st, c->Z, c->alpha, c->sf2, c->beta, Psi2, M, Mp, Q, c->Kmm, c->Kmm + mm,
+                     c->KmmKeep, (c->jitter_mask & 1) ? 1e-7 : 0.0, (c->jitter_mask & 2) ? 1e-7 : 0.0, c->gs, res_dd ? c->T2 : (double*)nullptr);
   GP_HIP(c, hipGetLastError());
   // one-panel problems (M, D <= 128): the panel kernel, then seven launches of tail_stage_kernel instead of fifteen kernels
   if (Mp == NB && Dp == NB && g_opt_gs_tail.load()) {
@@ -608,15 +736,24 @@ int run_global_step(gp_ctx* c) {
   g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
   const bool sk = ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0;
   if (sk) { g.splits = kSplitK; g.ws = ws; }
+  // the 128-tile kernel where it has >= 256 workgroups: split-k 8 at M = 1024 (measured there: 72-74 -> 63 us per product incl. the reduce; E E^T 56 -> 65: stays),
+  // M x M x M at M = 2048 (616 -> 392 us; the M x D products there have 128 tiles: 285 -> 337 us on it, stay on the small tiles)
+  const int bigMD = (g_opt_gemm_big.load() && Mp >= 1024 && (sk || (long)(Mp / TILE) * (Dp / TILE) >= 256)) ? 1 : 0;
+  const int bigMM = (g_opt_gemm_big.load() && Mp >= 1024 && (sk || (long)(Mp / TILE) * (Mp / TILE) >= 256)) ? 1 : 0;
+  g.big = bigMD;
   if (two) { GP_HIP(c, hipEventRecord(c->gev[0], st)); GP_HIP(c, hipStreamWaitEvent(s2, c->gev[0], 0)); }
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   // one refinement step of E with a double-double residual (PsiE is free until the next product); GPARML_REFINE_E=0 turns it off
   if (g_opt_refine_E.load()) {
-    hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(512), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
-                       c->PsiE, 0);
+    if (res_dd) {
+      hipLaunchKernelGGL((ddacc_residual_kernel<2, 8>), dim3(Dp / 64, Mp / 8), dim3(256), 0, st, c->T2, (long)Mp, c->E, (long)Dp, Mp, C, c->PsiE);
+    } else {
+      hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(512), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
+                         c->PsiE, 0);
+      if (M < Mp) GP_HIP(c, hipMemsetAsync(c->PsiE + (long)M * Dp, 0, (size_t)(Mp - M) * Dp * sizeof(double), st));
+    }
     GP_HIP(c, hipGetLastError());
-    if (M < Mp) GP_HIP(c, hipMemsetAsync(c->PsiE + (long)M * Dp, 0, (size_t)(Mp - M) * Dp * sizeof(double), st));
     g.A = P; g.lda = Mp; g.B = c->PsiE; g.ldb = Dp; g.C = c->E; g.ldc = Dp; g.beta = 1.0;
     launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
     g.beta = 0.0;
@@ -624,7 +761,7 @@ int run_global_step(gp_ctx* c) {
   g.A = Psi2; g.lda = Mp; g.B = c->E; g.ldb = Dp; g.C = c->PsiE; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
-  { const int sps = g.splits; if ((Dp / KC) % kSplitK != 0 || Dp < 256) g.splits = 1; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
+  { const int sps = g.splits; if ((Dp / KC) % kSplitK != 0 || Dp < 256) g.splits = 1; g.big = 0; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
   // G = Ki Psi2 with double-double accumulation (ddacc_gemm_kernel above: two rows per wave, eight k per trip -- same-box timing of six shapes
   // in profiles/r04_dd_variants.txt: +50 us at M = 512, +9 us at M = 128, +0.29 ms at M = 1024 over the float64 matrix-core product of r03, which
   // GPARML_DD_KIPSI2=0 or gp_debug_set_option("dd_kipsi2", 0) restores)
@@ -632,10 +769,10 @@ int run_global_step(gp_ctx* c) {
     hipLaunchKernelGGL((ddacc_gemm_kernel<2, 8>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp);
     GP_HIP(c, hipGetLastError());
   } else {
-    g.K = Mp; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
+    g.K = Mp; g.big = bigMM; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
     launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   }
-  g.K = Mp;
+  g.K = Mp; g.big = bigMM;
   g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;
   launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   if (two) { GP_HIP(c, hipEventRecord(c->gev[1], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[1], 0)); }
@@ -659,8 +796,12 @@ int run_global_step(gp_ctx* c) {
   hipLaunchKernelGGL(dots_kernel, dim3(DOT_BLOCKS, jobs.n), dim3(256), 0, st, jobs, dpart);
   hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, jobs, dpart, c->beta, c->sf2, (double)D, (double)c->N_global);
   // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
-  hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
-                     c->regime_A ? 1 : 0, c->gK, c->T2);
+  {
+    // the row's q-independent weights go through LDS (at most 32 KB: M <= 2048) and the inducing points are read transposed
+    const int lw = (M <= 2048) ? 1 : 0;
+    hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), lw ? (size_t)2 * 128 * ((M + 127) / 128) * 8 : 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z,
+                       c->alpha, M, Mp, Q, c->regime_A ? 1 : 0, c->gK, c->T2, lw, c->Zt);
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, s2, c->T2, M, Q, c->gK + (long)M * Q);
   if (two) { GP_HIP(c, hipEventRecord(c->gev[3], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[3], 0)); }
   GP_HIP(c, hipGetLastError());
@@ -680,7 +821,11 @@ extern "C" int gp_debug_set_option(const char* name, int value) {
   if (!std::strcmp(name, "gs_tail")) { g_opt_gs_tail.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "p2_i8")) { g_opt_p2_i8.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "i8_guard_strict")) { g_opt_i8_guard_strict.store(value ? 1 : 0); return GP_OK; }
-  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, p2_i8, gs_tail, i8_guard_strict)", name);
+  if (!std::strcmp(name, "xtx_tri")) { g_opt_xtx_tri.store(value ? 1 : 0); return GP_OK; }
+  if (!std::strcmp(name, "residual_dd")) { g_opt_residual_dd.store(value ? 1 : 0); return GP_OK; }
+  if (!std::strcmp(name, "gemm_big")) { g_opt_gemm_big.store(value ? 1 : 0); return GP_OK; }
+  if (!std::strcmp(name, "trtri_rec")) { g_opt_trtri_rec.store(value ? 1 : 0); return GP_OK; }
+  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, p2_i8, gs_tail, i8_guard_strict, xtx_tri, residual_dd, gemm_big, trtri_rec)", name);
 }
 
 extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet) {
@@ -695,7 +840,7 @@ extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double
   for (int i = 0; i < Mp; ++i) for (int k = 0; k < Mp; ++k) h[(long)i * Mp + k] = (i < n && k < n) ? A[(long)i * n + k] : (i == k ? 1.0 : 0.0);
   double *dA, *dLi, *dInv, *dT, *dS;
   GP_HIP(c, hipMalloc((void**)&dA, mm * 8)); GP_HIP(c, hipMalloc((void**)&dLi, mm * 8)); GP_HIP(c, hipMalloc((void**)&dInv, mm * 8));
-  GP_HIP(c, hipMalloc((void**)&dT, (long)NB * Mp * 8)); GP_HIP(c, hipMalloc((void**)&dS, 64));
+  GP_HIP(c, hipMalloc((void**)&dT, mm * 8)); GP_HIP(c, hipMalloc((void**)&dS, 64));
   GP_HIP(c, hipMemcpy(dA, h.data(), mm * 8, hipMemcpyHostToDevice));
   GP_HIP(c, hipMemset(dS, 0, 64));
   GP_HIP(c, hipMemset(dLi, 0, mm * 8));

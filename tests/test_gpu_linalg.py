@@ -32,7 +32,7 @@ def test_gemm_layouts(ta, tb, m, n, k):
     assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref)) * np.sqrt(k)
 
 
-@pytest.mark.parametrize('n', [1, 100, 128, 300, 700])
+@pytest.mark.parametrize('n', [1, 100, 128, 300, 640, 700, 900, 1100, 1400])     # 1, 1, 1, 3, 5, 6, 8, 9, 11 panels of 128: the inverse factor by halves meets truncated pairs at every level
 def test_cholesky_and_inverse(n):
     from gparml_amd import _lib
     lib = _lib.load()

@@ -86,7 +86,6 @@ struct gp_ctx {
   double* Z = nullptr;        // [Mp][Q] (rows >= M zero)
   double* alpha = nullptr;    // [Q]
   double* Zaug = nullptr;     // [Mp][CZp]
-  double* Zt = nullptr;       // [Q][Mp] the inducing points transposed (kmm_grads_kernel: lanes = inducing points)
   double* stats = nullptr;    // packed: Psi2 [Mp*Mp] | C [Mp*Dp] | scalars [SC_COUNT]
   bool stats_external = false;
   double* spack = nullptr;    // Psi2 upper triangle | C [M][D] | scalars: the all-reduce payload across processes (allocated on first use)

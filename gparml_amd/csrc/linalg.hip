@@ -394,73 +394,22 @@ __global__ void scalars_kernel(const double* sc, double* gs, DotJobs jobs, const
 }
 
 // row j by 128 threads (tid 0..127: two waves); red: 2 * QC doubles of LDS owned by these 128 threads.  `active` false: the threads only keep the
-// workgroup barriers in step (the fused tail runs two rows per 256-thread workgroup, and the last pair may be half empty).
+// workgroup barriers in step (the fused tail runs two rows per 256-thread workgroup, and the last pair may be half empty).  This is the form the
+// one-panel tail and kmm_grads_kernel run.
 constexpr int KG_QC = 8;
 __device__ __forceinline__ void kmm_grads_row(int j, bool active, int tid, double* red, const double* __restrict__ dFdK, const double* __restrict__ Kmm,
                                               const double* __restrict__ Bbar, const double* __restrict__ Psi2, const double* __restrict__ Z,
                                               const double* __restrict__ alpha, int M, int Mp, int Q, int regimeA, double* __restrict__ gZ,
-                                              double* __restrict__ gapart, double* symw = nullptr, const double* __restrict__ Zt = nullptr) {
+                                              double* __restrict__ gapart) {
   // latent dimensions in chunks of 8: the sums of a chunk stay in registers over the row, then one butterfly per sum and one
   // LDS hand-over between the two waves (the first version ran two 7-step workgroup reductions per latent dimension)
   constexpr int QC = KG_QC;
   const int lane = tid & 63, wave = tid >> 6;
-  // what does not depend on q, once per row: sym = (dF/dK + dF/dK^T)[j][m] K[j][m] and the alpha weight w (the column read dF/dK[m][j] is one cache
-  // line per element: at Q = 50 the loop below used to fetch it seven times -- 61 us per 1024 rows).  symw: 2 * 128 * ceil(M / 128) doubles of LDS,
-  // [t][tid] and [nm + t][tid]: every thread reads back only what it wrote (no barrier); nullptr: recomputed per chunk as before (the fused tail).
-  const bool inlds = symw != nullptr;
-  const int nm = (M + 127) / 128;
-  if (inlds && active) {
-    // four inducing points per trip with clamped addresses and zero weights for the ones past M: no branch around the loads, so all of a trip's loads
-    // are in flight together (one row was 64 dependent load round trips: 86 us per launch whatever the layout of Z)
-    for (int t0 = 0; t0 < nm; t0 += 4) {
-      double k[4], fjm[4], fmj[4], bb[4], pp[4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int m = min(tid + 128 * (t0 + tt), M - 1);
-        k[tt] = Kmm[(long)j * Mp + m];
-        fjm[tt] = dFdK[(long)j * Mp + m];
-        fmj[tt] = dFdK[(long)m * Mp + j];
-        if (!regimeA) { bb[tt] = Bbar[(long)j * Mp + m]; pp[tt] = Psi2[(long)j * Mp + m]; }
-      }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int t = t0 + tt;
-        if (t < nm) {
-          const bool ok = tid + 128 * t < M;
-          const double sym = (fjm[tt] + fmj[tt]) * k[tt];
-          double w = -0.5 * fjm[tt] * k[tt];
-          if (!regimeA) w += -0.25 * bb[tt] * pp[tt];
-          symw[t * 128 + tid] = ok ? sym : 0.0; symw[(nm + t) * 128 + tid] = ok ? w : 0.0;
-        }
-      }
-    }
-  }
   for (int q0 = 0; q0 < Q; q0 += QC) {
     double sz[QC], sa[QC], zj[QC];
 #pragma unroll
     for (int u = 0; u < QC; ++u) { sz[u] = 0.0; sa[u] = 0.0; zj[u] = (active && q0 + u < Q) ? Z[(long)j * Q + q0 + u] : 0.0; }
-    if (active && inlds) {
-      for (int t0 = 0; t0 < nm; t0 += 4) {
-        double zz[4][QC], sy[4], ww[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          const int t = t0 + tt, tc = t < nm ? t : nm - 1;
-          const int m = min(tid + 128 * tc, M - 1);
-          sy[tt] = t < nm ? symw[tc * 128 + tid] : 0.0;          // zero for an inducing point past M (and for the trip's unused slots):
-          ww[tt] = t < nm ? symw[(nm + tc) * 128 + tid] : 0.0;   // fma(0, dz, s) = s exactly, the sums are those of the loop over m < M
-#pragma unroll
-          for (int u = 0; u < QC; ++u) zz[tt][u] = (q0 + u < Q) ? Zt[(long)(q0 + u) * Mp + m] : 0.0;   // lanes = consecutive inducing points
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int u = 0; u < QC; ++u) {
-            const double dz = zj[u] - zz[tt][u];
-            sz[u] = fma(sy[tt], dz, sz[u]);
-            sa[u] = fma(ww[tt] * dz, dz, sa[u]);
-          }
-      }
-    } else if (active)
+    if (active)
       for (int m = tid; m < M; m += 128) {
         const double k = Kmm[(long)j * Mp + m];
         const double fjm = dFdK[(long)j * Mp + m];
@@ -499,11 +448,9 @@ __device__ __forceinline__ void kmm_grads_row(int j, bool active, int tid, doubl
 __global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict__ dFdK, const double* __restrict__ Kmm,
                                                          const double* __restrict__ Bbar, const double* __restrict__ Psi2,
                                                          const double* __restrict__ Z, const double* __restrict__ alpha, int M, int Mp,
-                                                         int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart, int lds_weights,
-                                                         const double* __restrict__ Zt) {
+                                                         int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart) {
   __shared__ double red[2 * KG_QC];
-  extern __shared__ __attribute__((aligned(16))) double symw_lds[];      // 2 * 128 * ceil(M / 128) doubles when Q needs more than one chunk, else none
-  kmm_grads_row(blockIdx.x, true, threadIdx.x, red, dFdK, Kmm, Bbar, Psi2, Z, alpha, M, Mp, Q, regimeA, gZ, gapart, lds_weights ? symw_lds : nullptr, lds_weights ? Zt : nullptr);
+  kmm_grads_row(blockIdx.x, true, threadIdx.x, red, dFdK, Kmm, Bbar, Psi2, Z, alpha, M, Mp, Q, regimeA, gZ, gapart);
 }
 // column q of part [rows][Q] summed by the calling 256-thread workgroup; red: 256 doubles of LDS
 __device__ __forceinline__ void colsum_block(const double* __restrict__ part, int rows, int Q, double* __restrict__ out, int q, double* red) {
@@ -796,12 +743,11 @@ int run_global_step(gp_ctx* c) {
   hipLaunchKernelGGL(dots_kernel, dim3(DOT_BLOCKS, jobs.n), dim3(256), 0, st, jobs, dpart);
   hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, jobs, dpart, c->beta, c->sf2, (double)D, (double)c->N_global);
   // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
-  {
-    // the row's q-independent weights go through LDS (at most 32 KB: M <= 2048) and the inducing points are read transposed
-    const int lw = (M <= 2048) ? 1 : 0;
-    hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), lw ? (size_t)2 * 128 * ((M + 127) / 128) * 8 : 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z,
-                       c->alpha, M, Mp, Q, c->regime_A ? 1 : 0, c->gK, c->T2, lw, c->Zt);
-  }
+  // (r05: 62 us at M = 1024, Q = 50 on some boxes of the pool, 137-146 us on others, the other kernels of the step within 3 %.  Six variants changed
+  // nothing on the same box: the q-independent weights hoisted into registers or LDS, Z read transposed, loads batched four inducing points deep, four rows
+  // per workgroup, the column of dF/dK from a transposed copy, a reduce-scatter in place of the sixteen butterflies.  Left as it was.)
+  hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
+                     c->regime_A ? 1 : 0, c->gK, c->T2);
   hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, s2, c->T2, M, Q, c->gK + (long)M * Q);
   if (two) { GP_HIP(c, hipEventRecord(c->gev[3], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[3], 0)); }
   GP_HIP(c, hipGetLastError());

@@ -42,6 +42,28 @@
 #define A_CVTI(D) "v_cvt_i32_f64 " #D ", %10\n\t"
 #define A_MOVDPP(D) "v_mov_b32_dpp " #D ", " #D " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 #define A_MOV32(D) "v_mov_b32 " #D ", %8\n\t"
+// the accumulate form of the pair kernels' exponent, fma(s, v, acc): a 64-bit SGPR operand; and the same with only FOUR independent accumulators
+// (the four points of a trip): does a dependent v_fma_f64 issue every 4 x 4.3 cycles?
+#define KERNEL64S(NAME, ASM, NACC)                                                                                      \
+  __global__ void __launch_bounds__(256) NAME(int iters, double* out) {                                                 \
+    double d0 = threadIdx.x, d1 = 1.5, d2 = 2.5, d3 = 3.5, d4 = 4.5, d5 = 5.5, d6 = 6.5, d7 = 7.5, b = 0.5;                \
+    double sv = __builtin_bit_cast(double, (long)__builtin_amdgcn_readfirstlane(iters) | 0x3ff0000000000000L);            \
+    for (int it = 0; it < iters; ++it) {                                                                               \
+      if (NACC == 8)                                                                                                   \
+        asm volatile(ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%4) ASM(%5) ASM(%6) ASM(%7) ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%4) ASM(%5) ASM(%6) ASM(%7) \
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "s"(sv), "v"(b));  \
+      else                                                                                                             \
+        asm volatile(ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%0) ASM(%1) ASM(%2) ASM(%3) \
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "s"(sv), "v"(b));  \
+    }                                                                                                                  \
+    if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 == 123.456) out[0] = d0;                                                 \
+  }
+#define A_FMAS(D) "v_fma_f64 " #D ", %8, %9, " #D "\n\t"
+#define A_FMAV(D) "v_fma_f64 " #D ", %9, %9, " #D "\n\t"
+KERNEL64S(k_fma_sgpr8, A_FMAS, 8)
+KERNEL64S(k_fma_sgpr4, A_FMAS, 4)
+KERNEL64S(k_fma_vacc8, A_FMAV, 8)
+KERNEL64S(k_fma_vacc4, A_FMAV, 4)
 KERNEL64(k_fma, A_FMA)
 KERNEL64(k_mul, A_MUL)
 KERNEL64(k_add, A_ADD)
@@ -63,20 +85,21 @@ int main() {
   double* out; hipMalloc(&out, 64);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   struct { const char* name; void (*k)(int, double*); } ks[] = {
-      {"v_fma_f64", k_fma}, {"v_mul_f64", k_mul}, {"v_add_f64", k_add}, {"v_ldexp_f64", k_ldexp}, {"v_rndne_f64", k_rndne}, {"v_mov_b64", k_mov64},
+      {"v_fma_f64", k_fma}, {"v_fma_f64 acc += s * v (8 accumulators)", k_fma_sgpr8}, {"v_fma_f64 acc += s * v (4 accumulators)", k_fma_sgpr4},
+      {"v_fma_f64 acc += v * v (8 accumulators)", k_fma_vacc8}, {"v_fma_f64 acc += v * v (4 accumulators)", k_fma_vacc4}, {"v_mul_f64", k_mul}, {"v_add_f64", k_add}, {"v_ldexp_f64", k_ldexp}, {"v_rndne_f64", k_rndne}, {"v_mov_b64", k_mov64},
       {"v_cvt_i32_f64", k_cvti}, {"v_add_u32", k_addu}, {"v_and_b32", k_and}, {"v_lshlrev_b32", k_lshl}, {"v_lshl_add_u32", k_lshladd}, {"v_mul_lo_u32", k_mullo},
       {"v_bfe_u32", k_bfe}, {"v_cndmask_b32", k_cndmask}, {"v_mov_b32", k_mov32}, {"v_mov_b32_dpp quad_perm", k_movdpp}};
   const int iters = 20000;
   // clock: v_fma_f64 is known at 4.3 cycles per instruction when the part holds its clock; report everything relative to the wall clock at 2.4 GHz nominal
   for (auto& k : ks)
-    for (int wps : {1, 4}) {
+    for (int wps : {1, 2, 4, 8}) {
       const int blocks = 256 * wps;
       hipLaunchKernelGGL(k.k, dim3(blocks), dim3(256), 0, 0, 100, out);
       hipEventRecord(e0);
       hipLaunchKernelGGL(k.k, dim3(blocks), dim3(256), 0, 0, iters, out);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      printf("%-26s %d wave(s) per SIMD: %6.2f cycles per instruction per SIMD at 2.4 GHz\n", k.name, wps, ms * 1e-3 * 2.4e9 / (16.0 * iters * wps));
+      printf("%-42s %d wave(s) per SIMD: %6.2f cycles per instruction per SIMD at 2.4 GHz\n", k.name, wps, ms * 1e-3 * 2.4e9 / (16.0 * iters * wps));
     }
   return 0;
 }

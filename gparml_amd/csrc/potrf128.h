@@ -252,8 +252,12 @@ __global__ void __launch_bounds__(512) potrf_trinv128_kernel(double* A, long ld,
       block_sync_lds();
     }
     POTRF_STAMP(4 + 5 * s);
-    // ---- rank-32 update of the trailing lower 16x16 tiles
-    for (int t = wave; t < nrb * (nrb + 1) / 2; t += 8) {
+    // ---- rank-32 update of the trailing lower 16x16 tiles.  Look-ahead (r05): the first pass (tiles 0..7, one per wave) contains the three tiles
+    // of the NEXT diagonal sub-block (0, 1, 2 in the row-wise enumeration of the lower triangle); behind the barrier that follows it wave 0 goes
+    // straight to that sub-block's factorisation while waves 1..7 finish the remaining tiles (rows from o + 64 on: disjoint from what wave 0 reads and
+    // writes) and meet it at the barrier behind the factorisation -- the next solve reads those tiles only after that barrier.  The serial
+    // factorisation chain (38 % of the kernel) used to wait for all of the update.
+    auto update_tile = [&](int t) {
       int r16 = 0, rem = t;
       while (rem > r16) { rem -= r16 + 1; ++r16; }
       const int c16 = rem;
@@ -262,8 +266,12 @@ __global__ void __launch_bounds__(512) potrf_trinv128_kernel(double* A, long ld,
       const int R = o + 32 + 16 * r16 + t16_row(lane);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) S[R * PLD + o + 32 + 16 * c16 + t16_col(jj, lane)] -= acc[jj];
-    }
+    };
+    const int ntile = nrb * (nrb + 1) / 2;
+    if (wave < ntile) update_tile(wave);
     block_sync_lds();
+    if (wave > 0)
+      for (int t = 8 + (wave - 1); t < ntile; t += 7) update_tile(t);
     POTRF_STAMP(5 + 5 * s);
   }
   // ---- off-diagonal part of the inverse: X21 = -X22 (L21 X11) for block size 32 (two pairs) and 64

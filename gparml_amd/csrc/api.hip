@@ -60,7 +60,7 @@ __global__ void scale_kernel(double* x, long n, double f) {
 // Zaug[m] = [1, z_m, z_m^2] (rows >= M zero), Z padded copy
 // Zin / alpha_in are read straight from the pinned host slot of gp_set_globals (mapped memory: M Q + Q doubles over the bus, no copy commands)
 __global__ void zaug_kernel(const double* __restrict__ Zin, const double* __restrict__ alpha_in, int M, int Mp, int Q, int CZp, double* __restrict__ Z,
-                            double* __restrict__ Zaug, double* __restrict__ alpha) {
+                            double* __restrict__ Zaug, double* __restrict__ alpha, double* __restrict__ Zt) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m < Q) alpha[m] = alpha_in[m];
   if (m >= Mp) return;
@@ -68,6 +68,7 @@ __global__ void zaug_kernel(const double* __restrict__ Zin, const double* __rest
   for (int q = 0; q < Q; ++q) {
     const double z = (m < M) ? Zin[(long)m * Q + q] : 0.0;
     Z[(long)m * Q + q] = z;
+    Zt[(long)q * Mp + m] = z;
     if (m < M) { Zaug[(long)m * CZp + 1 + q] = z; Zaug[(long)m * CZp + 1 + Q + q] = z * z; }
   }
   if (m < M) Zaug[(long)m * CZp] = 1.0;
@@ -117,7 +118,7 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   A(&c->Kaug, (size_t)Np * c->LDK);
   A(&c->Xmu, (size_t)N_s * Q); A(&c->Xs, (size_t)N_s * Q); A(&c->dir, (size_t)2 * N_s * Q);
   A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->U, (size_t)Np * Q); A(&c->PU, (size_t)Np * (2 * std::max(psi1_qp(Q), 2) + 2)); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
-  A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp + 8);   // + 8: p2_gen8_kernel stages feature columns in groups of eight
+  A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp + 8); A(&c->Zt, (size_t)Mp * Q);   // + 8: p2_gen8_kernel stages feature columns in groups of eight
   A(&c->stats, (size_t)Mp * Mp + Mp * Dp + SC_COUNT);
   A(&c->grads, (size_t)M * Q + Q);
   // phase-1 tile table: Psi2 upper tiles first, then the C tiles
@@ -139,6 +140,14 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   c->kl_blocks = blocks_for(Np);
   A(&c->klpart, (size_t)c->kl_blocks + 8192);
   A(&c->Kmm, (size_t)2 * Mp * Mp); A(&c->Lmat, (size_t)2 * Mp * Mp); A(&c->Linv, (size_t)2 * Mp * Mp); A(&c->Inv, (size_t)2 * Mp * Mp);
+  if (Mp >= 512 && Mp <= 2048) {
+    // gsi8.hip: ten digit planes of W = [A | B] for the larger of the two products (K_mm^-1 | Psi2: 2 Mp columns; K_mm + beta Psi2 | E: Mp + Dp), and W's column scales
+    c->gss_count = (size_t)Mp + std::max(Mp, Dp);
+    c->gsd_bytes = (size_t)10 * Mp * c->gss_count;
+    double* tmp = nullptr;
+    A(&tmp, c->gsd_bytes / 8); c->gsd = reinterpret_cast<int8_t*>(tmp);
+    A(&c->gss, c->gss_count);
+  }
   A(&c->KmmKeep, (size_t)Mp * Mp); A(&c->T1, (size_t)Mp * std::max<long>(std::max(Mp, Dp), 256)); A(&c->T2, (size_t)Mp * std::max(Mp, Dp));
   A(&c->dFdK, (size_t)Mp * Mp); A(&c->Bbar, (size_t)Mp * Mp);
   A(&c->E, (size_t)Mp * Dp); A(&c->PsiE, (size_t)Mp * Dp); A(&c->Abar, (size_t)Mp * Dp);
@@ -166,7 +175,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (!c) return GP_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->U, c->PU, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug,
+  double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->U, c->PU, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug, c->Zt, reinterpret_cast<double*>(c->gsd), c->gss,
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
                     c->HZp, c->gXmu, c->gXs, c->gapart, c->hgpart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
@@ -336,7 +345,7 @@ extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const doub
   double* dslot = nullptr;
   GP_HIP(c, hipHostGetDevicePointer((void**)&dslot, c->h_glob[slot], 0));
   hipLaunchKernelGGL(zaug_kernel, dim3((std::max(c->Mp, c->Q) + 255) / 256), dim3(256), 0, c->stream, dslot, dslot + nz, c->M, c->Mp, c->Q, c->CZp, c->Z,
-                     c->Zaug, c->alpha);
+                     c->Zaug, c->alpha, c->Zt);
   GP_HIP(c, hipGetLastError());
   c->glob_epoch[slot] = c->sync_epoch;                      // the slot may be rewritten once a later stream synchronisation has passed
   c->glob_slot = slot ^ 1;

@@ -86,6 +86,11 @@ struct gp_ctx {
   double* Z = nullptr;        // [Mp][Q] (rows >= M zero)
   double* alpha = nullptr;    // [Q]
   double* Zaug = nullptr;     // [Mp][CZp]
+  double* Zt = nullptr;       // [Q][Mp] the inducing points transposed (kmm_grads_lds_kernel: lanes = inducing points)
+  int8_t* gsd = nullptr;      // gsi8.hip (M >= 1024): digit planes of the global step's two double-double-grade products on the int8 matrix core
+  size_t gsd_bytes = 0;
+  double* gss = nullptr;      // their column scales
+  size_t gss_count = 0;
   double* stats = nullptr;    // packed: Psi2 [Mp*Mp] | C [Mp*Dp] | scalars [SC_COUNT]
   bool stats_external = false;
   double* spack = nullptr;    // Psi2 upper triangle | C [M][D] | scalars: the all-reduce payload across processes (allocated on first use)
@@ -255,6 +260,10 @@ int compat_build(gp_ctx* c, int which, double** out, long* count);
 void comm_free(gp_ctx* c);
 // linalg.hip
 int run_global_step(gp_ctx* c);
+// gsi8.hip: the global step's two double-double-grade products on the int8 matrix core (M >= 1024)
+bool gs_i8_wanted(const gp_ctx* c);
+int run_gs_i8_product(gp_ctx* c, hipStream_t st, const double* A, long lda, int nA, const double* B, long ldb, int nB, int K, double* out, long ldo,
+                      const double* Csub);
 int check_global(gp_ctx* c);
 // the same with the scalars + failure flags already on the host (h = [GS_COUNT + 8] doubles, or NULL when nothing is pending)
 int check_global_from(gp_ctx* c, const double* h);
@@ -262,8 +271,8 @@ int check_global_from(gp_ctx* c, const double* h);
 // Inv = Linv^T Linv reads the whole matrix.  gp_create allocates Linv zeroed and nothing else writes those blocks; the test hook
 // gp_debug_potrf_inverse memsets its own buffer.  A caller that hands in a reused scratch buffer must clear it first.
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,
-                          double* Twork /*[batch][128][Mp]*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/,
-                          double* splitk_ws /*may be NULL*/);
+                          double* Twork /*batch * Mp * Mp / 2 doubles*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/,
+                          double* splitk_ws /*may be NULL*/, size_t splitk_cap = 0);
 }  // namespace gp
 
 // event i of the context's timing set, if the timing level asks for it (levels: gp_ctx::timing)

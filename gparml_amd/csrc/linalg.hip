@@ -24,6 +24,7 @@ std::atomic<int> g_opt_refine_E{env_on("GPARML_REFINE_E") ? 1 : 0};
 extern std::atomic<int> g_opt_p1_i8;      // p1i8.hip
 extern std::atomic<int> g_opt_i8_guard_strict;
 extern std::atomic<int> g_opt_p2_i8;      // p2i8.hip
+extern std::atomic<int> g_opt_gs_i8;      // gsi8.hip
 
 // r05, the global step at M >= 1024 (each switchable for same-box A/B through gp_debug_set_option):
 std::atomic<int> g_opt_xtx_tri{1};       // A^-1 = X^T X from its lower tiles, k from the tile's first non-zero row, mirrored store (bit-identical)
@@ -31,13 +32,20 @@ std::atomic<int> g_opt_residual_dd{1};   // the refinement residual through ddac
 std::atomic<int> g_opt_trtri_rec{1};     // L^-1 by halves: two batched launches per level instead of two per block row
 std::atomic<int> g_opt_gemm_big{1};      // the M x M x {M, D} products on the 128 x 128-tile kernel (split-k 8 at M = 1024) for Mp >= 1024
 
-constexpr int kSplitK = 8;   // split-k factor of the M x M x M products of the global step (latency-bound: 16 tiles alone fill 6 % of the chip)
+constexpr int kSplitK = 8;
+// split-k factor for a product of `tiles` 128 x 128 output tiles (batch included) with contraction length K on the 128-tile kernel: about 512 workgroups
+// (two per CU), a power of two <= 8 that divides the number of k-chunks, and whose partial tiles fit the workspace (cap doubles)
+static int choose_splits(long tiles, int K, size_t cap) {
+  int s = 8;
+  while (s > 1 && (tiles * s > 512 || (K / KC) % s != 0 || (size_t)tiles * s * TILE * TILE > cap)) s >>= 1;
+  return s;
+}   // split-k factor of the M x M x M products of the global step (latency-bound: 16 tiles alone fill 6 % of the chip)
 
 
 
 // A: [batch][Mp][Mp] SPD in, lower Cholesky factor out (upper zeroed); Linv: L^-1; Inv: A^-1; Twork: batch * Mp * Mp / 2 doubles
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A, double* Linv, double* Inv, double* Twork,
-                          double* logdet2, double* fail_flag, double* splitk_ws) {
+                          double* logdet2, double* fail_flag, double* splitk_ws, size_t splitk_cap) {
   const int nt = Mp / NB;
   const long ld = Mp, bs = (long)Mp * Mp;
   // a per-device attribute: set on every call (cheap) rather than once per process -- contexts may live on several GPUs
@@ -114,8 +122,14 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
   r.C = Inv; r.ldc = ld; r.sC = bs;
   r.K = Mp; r.alpha = 1.0; r.beta = 0.0; r.tri = 0;
   if (g_opt_xtx_tri.load()) { r.tri = 1; r.klow = 1; r.mirror = 1; }
-  if (splitk_ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0) { r.splits = kSplitK; r.ws = splitk_ws; }
-  r.big = (g_opt_gemm_big.load() && Mp >= 1024 && (r.splits > 1 || (long)(Mp / TILE) * (Mp / TILE) * batch >= 256)) ? 1 : 0;
+  if (g_opt_gemm_big.load() && Mp >= 1024 && splitk_ws) {
+    const long tiles = (long)(Mp / TILE) * (Mp / TILE) * batch;
+    r.splits = choose_splits(tiles, Mp, splitk_cap); r.ws = splitk_ws;
+    r.big = tiles * r.splits >= 256 ? 1 : 0;
+    if (!r.big) r.splits = 1;
+  } else if (splitk_ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0 && (size_t)batch * (Mp / TILE) * (Mp / TILE) * kSplitK * TILE * TILE <= splitk_cap) {
+    r.splits = kSplitK; r.ws = splitk_ws;       // (ignored by the small-tile kernel that serves these sizes)
+  }
   launch_gemm(st, FREE_CONTIG, FREE_CONTIG, Mp, Mp, batch, r);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -452,6 +466,84 @@ __global__ void __launch_bounds__(128) kmm_grads_kernel(const double* __restrict
   __shared__ double red[2 * KG_QC];
   kmm_grads_row(blockIdx.x, true, threadIdx.x, red, dFdK, Kmm, Bbar, Psi2, Z, alpha, M, Mp, Q, regimeA, gZ, gapart);
 }
+// The same row with the q-independent weights computed once (they wait in LDS: [t][tid] and [nm + t][tid], every thread reads back only what it wrote), the
+// inducing points read from the transposed copy Zt [Q][Mp] (lanes = consecutive inducing points: one 512-byte run per load instead of 64 cache lines), and
+// four inducing points per trip with clamped addresses and zero weights past M (fma(0, dz, s) = s exactly), so a trip's loads are in flight together.
+// Same sums in the same order as kmm_grads_row: same bits.  Same-box A/B against the plain form at M = 1024, Q = 50: see run_global_step.
+__global__ void __launch_bounds__(128) kmm_grads_lds_kernel(const double* __restrict__ dFdK, const double* __restrict__ Kmm,
+                                                             const double* __restrict__ Bbar, const double* __restrict__ Psi2,
+                                                             const double* __restrict__ Z, const double* __restrict__ Zt, const double* __restrict__ alpha,
+                                                             int M, int Mp, int Q, int regimeA, double* __restrict__ gZ, double* __restrict__ gapart) {
+  constexpr int QC = KG_QC;
+  __shared__ double red[2 * KG_QC];
+  extern __shared__ __attribute__((aligned(16))) double symw[];      // 2 * 128 * ceil(M / 128) doubles
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nm = (M + 127) / 128;
+  for (int t0 = 0; t0 < nm; t0 += 4) {
+    double k[4], fjm[4], fmj[4], bb[4], pp[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int m = min(tid + 128 * (t0 + tt), M - 1);
+      k[tt] = Kmm[(long)j * Mp + m];
+      fjm[tt] = dFdK[(long)j * Mp + m];
+      fmj[tt] = dFdK[(long)m * Mp + j];
+      if (!regimeA) { bb[tt] = Bbar[(long)j * Mp + m]; pp[tt] = Psi2[(long)j * Mp + m]; }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int t = t0 + tt;
+      if (t < nm) {
+        const bool ok = tid + 128 * t < M;
+        const double sym = (fjm[tt] + fmj[tt]) * k[tt];
+        double w = -0.5 * fjm[tt] * k[tt];
+        if (!regimeA) w += -0.25 * bb[tt] * pp[tt];
+        symw[t * 128 + tid] = ok ? sym : 0.0; symw[(nm + t) * 128 + tid] = ok ? w : 0.0;
+      }
+    }
+  }
+  for (int q0 = 0; q0 < Q; q0 += QC) {
+    double sz[QC], sa[QC], zj[QC];
+#pragma unroll
+    for (int u = 0; u < QC; ++u) { sz[u] = 0.0; sa[u] = 0.0; zj[u] = (q0 + u < Q) ? Z[(long)j * Q + q0 + u] : 0.0; }
+    for (int t0 = 0; t0 < nm; t0 += 4) {
+      double zz[4][QC], sy[4], ww[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int t = t0 + tt, tc = t < nm ? t : nm - 1;
+        const int m = min(tid + 128 * tc, M - 1);
+        sy[tt] = t < nm ? symw[tc * 128 + tid] : 0.0;
+        ww[tt] = t < nm ? symw[(nm + tc) * 128 + tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < QC; ++u) zz[tt][u] = (q0 + u < Q) ? Zt[(long)(q0 + u) * Mp + m] : 0.0;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int u = 0; u < QC; ++u) {
+          const double dz = zj[u] - zz[tt][u];
+          sz[u] = fma(sy[tt], dz, sz[u]);
+          sa[u] = fma(ww[tt] * dz, dz, sa[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QC; ++u)
+      for (int sh = 32; sh > 0; sh >>= 1) { sz[u] += __shfl_xor(sz[u], sh); sa[u] += __shfl_xor(sa[u], sh); }
+    if (wave == 1 && lane == 0) {
+#pragma unroll
+      for (int u = 0; u < QC; ++u) { red[u] = sz[u]; red[QC + u] = sa[u]; }
+    }
+    __syncthreads();
+    if (wave == 0 && lane == 0) {
+#pragma unroll
+      for (int u = 0; u < QC; ++u)
+        if (q0 + u < Q) {
+          gZ[(long)j * Q + q0 + u] = -alpha[q0 + u] * (sz[u] + red[u]);
+          gapart[(long)j * Q + q0 + u] = sa[u] + red[QC + u];
+        }
+    }
+    __syncthreads();
+  }
+}
 // column q of part [rows][Q] summed by the calling 256-thread workgroup; red: 256 doubles of LDS
 __device__ __forceinline__ void colsum_block(const double* __restrict__ part, int rows, int Q, double* __restrict__ out, int q, double* red) {
   double s = 0.0;
@@ -627,7 +719,8 @@ int run_global_step(gp_ctx* c) {
   c->gs_status = GP_OK;
   double* failf = c->gs + GS_COUNT;  // [2]
   // T2 is free until G = K_mm^-1 Psi2 is formed: it keeps A for the double-double residual of the refinement step
-  const bool res_dd = g_opt_refine_E.load() && g_opt_residual_dd.load() && Mp >= 256 && Dp >= 512;   // narrow E: too few waves (M = 512, D = 100: +21 us)
+  const bool gi8 = gs_i8_wanted(c);            // gsi8.hip: both double-double products on the int8 matrix core (M >= 1024)
+  const bool res_dd = g_opt_refine_E.load() && ((g_opt_residual_dd.load() && Mp >= 256 && Dp >= 512) || gi8);   // narrow E: too few waves (M = 512, D = 100: +21 us)
   hipLaunchKernelGGL(build_kmm_kernel, dim3(Mp / 64, Mp / 16), dim3(256), 0, st, c->Z, c->alpha, c->sf2, c->beta, Psi2, M, Mp, Q, c->Kmm, c->Kmm + mm,
                      c->KmmKeep, (c->jitter_mask & 1) ? 1e-7 : 0.0, (c->jitter_mask & 2) ? 1e-7 : 0.0, c->gs, res_dd ? c->T2 : (double*)nullptr);
   GP_HIP(c, hipGetLastError());
@@ -662,8 +755,9 @@ int run_global_step(gp_ctx* c) {
   }
   // factorise [Kmm ; A] in place, invert.  T1 is the 2 x 128 x Mp work panel.
   // split-k workspace: the phase-1 partial buffer is free during the global step (>= 600 tiles)
-  double* ws = ((size_t)2 * (Mp / TILE) * std::max(Mp, Dp) / TILE * kSplitK * TILE * TILE <= c->part_doubles) ? c->part : nullptr;
-  int rc = potrf_inverse_batched(c, st, Mp, 2, c->Kmm, c->Linv, c->Inv, c->T1, c->gs + GS_LOGDET_K, failf, ws);
+  double* ws = c->part;
+  const size_t wcap = c->part_doubles;
+  int rc = potrf_inverse_batched(c, st, Mp, 2, c->Kmm, c->Linv, c->Inv, c->T1, c->gs + GS_LOGDET_K, failf, ws, wcap);
   if (rc != GP_OK) return rc;
   double* Ki = c->Inv;
   double* P = c->Inv + mm;
@@ -681,19 +775,23 @@ int run_global_step(gp_ctx* c) {
   hipStream_t s2 = two ? c->side : st;
   GemmP g;
   g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
-  const bool sk = ws && Mp >= 256 && Mp <= 1024 && (Mp / KC) % kSplitK == 0;
-  if (sk) { g.splits = kSplitK; g.ws = ws; }
-  // the 128-tile kernel where it has >= 256 workgroups: split-k 8 at M = 1024 (measured there: 72-74 -> 63 us per product incl. the reduce; E E^T 56 -> 65: stays),
-  // M x M x M at M = 2048 (616 -> 392 us; the M x D products there have 128 tiles: 285 -> 337 us on it, stay on the small tiles)
-  const int bigMD = (g_opt_gemm_big.load() && Mp >= 1024 && (sk || (long)(Mp / TILE) * (Dp / TILE) >= 256)) ? 1 : 0;
-  const int bigMM = (g_opt_gemm_big.load() && Mp >= 1024 && (sk || (long)(Mp / TILE) * (Mp / TILE) >= 256)) ? 1 : 0;
-  g.big = bigMD;
+  // the 128-tile kernel with split-k where that gives >= 256 workgroups (M >= 1024: 72-74 -> 63 us per product incl. the reduce at M = 1024; at M = 2048 the
+  // M x M x M product 616 -> 392 us without a split, the M x M x D ones have 128 tiles and lose to the small tiles unless split); E E^T stays on the small tiles
+  const bool bigok = g_opt_gemm_big.load() && Mp >= 1024 && ws;
+  const int spMD = bigok ? choose_splits((long)(Mp / TILE) * (Dp / TILE), Mp, wcap) : 1;
+  const int spMM = bigok ? choose_splits((long)(Mp / TILE) * (Mp / TILE), Mp, wcap) : 1;
+  const int bigMD = (bigok && (long)(Mp / TILE) * (Dp / TILE) * spMD >= 256) ? 1 : 0;
+  const int bigMM = (bigok && (long)(Mp / TILE) * (Mp / TILE) * spMM >= 256) ? 1 : 0;
+  g.ws = ws;
+  g.big = bigMD; g.splits = bigMD ? spMD : 1;
   if (two) { GP_HIP(c, hipEventRecord(c->gev[0], st)); GP_HIP(c, hipStreamWaitEvent(s2, c->gev[0], 0)); }
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   // one refinement step of E with a double-double residual (PsiE is free until the next product); GPARML_REFINE_E=0 turns it off
   if (g_opt_refine_E.load()) {
-    if (res_dd) {
+    if (gi8) {
+      GP_TRY_RC(run_gs_i8_product(c, st, c->T2, (long)Mp, Mp, c->E, (long)Dp, Dp, Mp, c->PsiE, (long)Dp, C));
+    } else if (res_dd) {
       hipLaunchKernelGGL((ddacc_residual_kernel<2, 8>), dim3(Dp / 64, Mp / 8), dim3(256), 0, st, c->T2, (long)Mp, c->E, (long)Dp, Mp, C, c->PsiE);
     } else {
       hipLaunchKernelGGL(solve_residual_kernel, dim3(M), dim3(512), 0, st, c->KmmKeep, Psi2, c->beta, (c->jitter_mask & 2) ? 1e-7 : 0.0, C, c->E, M, Mp, Dp,
@@ -708,18 +806,20 @@ int run_global_step(gp_ctx* c) {
   g.A = Psi2; g.lda = Mp; g.B = c->E; g.ldb = Dp; g.C = c->PsiE; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   g.K = Dp; g.A = c->E; g.lda = Dp; g.B = c->E; g.ldb = Dp; g.C = c->T1; g.ldc = Mp;   // B(k,j) = E[j][k] -> K_CONTIG
-  { const int sps = g.splits; if ((Dp / KC) % kSplitK != 0 || Dp < 256) g.splits = 1; g.big = 0; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
+  { const int sps = g.splits; g.splits = 1; g.big = 0; launch_gemm(st, K_CONTIG, K_CONTIG, Mp, Mp, 1, g); g.splits = sps; }
   // G = Ki Psi2 with double-double accumulation (ddacc_gemm_kernel above: two rows per wave, eight k per trip -- same-box timing of six shapes
   // in profiles/r04_dd_variants.txt: +50 us at M = 512, +9 us at M = 128, +0.29 ms at M = 1024 over the float64 matrix-core product of r03, which
   // GPARML_DD_KIPSI2=0 or gp_debug_set_option("dd_kipsi2", 0) restores)
-  if (g_opt_dd_kipsi2.load()) {
+  if (g_opt_dd_kipsi2.load() && gi8) {
+    GP_TRY_RC(run_gs_i8_product(c, s2, Ki, (long)Mp, Mp, Psi2, (long)Mp, Mp, Mp, c->T2, (long)Mp, nullptr));
+  } else if (g_opt_dd_kipsi2.load()) {
     hipLaunchKernelGGL((ddacc_gemm_kernel<2, 8>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp);
     GP_HIP(c, hipGetLastError());
   } else {
-    g.K = Mp; g.big = bigMM; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
+    g.K = Mp; g.big = bigMM; g.splits = bigMM ? spMM : 1; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
     launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   }
-  g.K = Mp; g.big = bigMM;
+  g.K = Mp; g.big = bigMM; g.splits = bigMM ? spMM : 1;
   g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;
   launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   if (two) { GP_HIP(c, hipEventRecord(c->gev[1], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[1], 0)); }
@@ -743,11 +843,13 @@ int run_global_step(gp_ctx* c) {
   hipLaunchKernelGGL(dots_kernel, dim3(DOT_BLOCKS, jobs.n), dim3(256), 0, st, jobs, dpart);
   hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, jobs, dpart, c->beta, c->sf2, (double)D, (double)c->N_global);
   // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
-  // (r05: 62 us at M = 1024, Q = 50 on some boxes of the pool, 137-146 us on others, the other kernels of the step within 3 %.  Six variants changed
-  // nothing on the same box: the q-independent weights hoisted into registers or LDS, Z read transposed, loads batched four inducing points deep, four rows
-  // per workgroup, the column of dF/dK from a transposed copy, a reduce-scatter in place of the sixteen butterflies.  Left as it was.)
-  hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
-                     c->regime_A ? 1 : 0, c->gK, c->T2);
+  static const bool kmm_lds = [] { const char* e = getenv("GPARML_KMM_LDS"); return !(e && e[0] == '0'); }();
+  if (kmm_lds && M <= 2048)
+    hipLaunchKernelGGL(kmm_grads_lds_kernel, dim3(M), dim3(128), (size_t)2 * 128 * ((M + 127) / 128) * sizeof(double), s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z,
+                       c->Zt, c->alpha, M, Mp, Q, c->regime_A ? 1 : 0, c->gK, c->T2);
+  else
+    hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
+                       c->regime_A ? 1 : 0, c->gK, c->T2);
   hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, s2, c->T2, M, Q, c->gK + (long)M * Q);
   if (two) { GP_HIP(c, hipEventRecord(c->gev[3], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[3], 0)); }
   GP_HIP(c, hipGetLastError());
@@ -771,7 +873,8 @@ extern "C" int gp_debug_set_option(const char* name, int value) {
   if (!std::strcmp(name, "residual_dd")) { g_opt_residual_dd.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "gemm_big")) { g_opt_gemm_big.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "trtri_rec")) { g_opt_trtri_rec.store(value ? 1 : 0); return GP_OK; }
-  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, p2_i8, gs_tail, i8_guard_strict, xtx_tri, residual_dd, gemm_big, trtri_rec)", name);
+  if (!std::strcmp(name, "gs_i8")) { g_opt_gs_i8.store(value ? 1 : 0); return GP_OK; }
+  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, p2_i8, gs_tail, i8_guard_strict, xtx_tri, residual_dd, gemm_big, trtri_rec, gs_i8)", name);
 }
 
 extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet) {

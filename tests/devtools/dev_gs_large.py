@@ -13,7 +13,7 @@ from gparml_amd import _lib
 from gparml_amd.engine import ShardEngine
 from oracle import factorised as Fz
 
-OPTS = ('xtx_tri', 'residual_dd', 'gemm_big', 'trtri_rec')
+OPTS = ('xtx_tri', 'residual_dd', 'gemm_big', 'trtri_rec', 'gs_i8')
 
 
 def setopt(**kw):

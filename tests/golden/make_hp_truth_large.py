@@ -20,6 +20,7 @@ block's largest magnitude), cond(Kmm), cond(Kmm + beta Psi2).  Inputs are NOT st
 bench.synthetic(N, D, M, Q, seed=100) and check the checksums.
 
 Usage (build container, 8 cores: ~10 min at N = 1e6):  python tests/golden/make_hp_truth_large.py [N [seed [z_seed]]]
+  python tests/golden/make_hp_truth_large.py 50000 100 -1 1024     (M = 1024: hp_truth_M1024_N50000.npz)
 (seed 100 with the benchmark's own inducing points is the default and keeps the file name hp_truth_large_N<N>.npz; other draws are
 stored as hp_truth_large_N<N>_s<seed>_z<z_seed>.npz -- round 4: four more data / inducing-point draws at both sizes)
 """
@@ -64,7 +65,9 @@ def main():
     N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
     D, M, Q = 100, 512, 10
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    z_seed = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    z_seed = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) >= 0 else None
+    if len(sys.argv) > 4:
+        M = int(sys.argv[4])          # round 5: M = 1024 (the global step's int8 products, csrc/gsi8.hip) -> hp_truth_M1024_N<N>.npz
     d = bench.synthetic(N, D, M, Q, seed=seed, z_seed=z_seed)
     assert np.all(d['X_S'] == 0)
     exe = os.path.join(ROOT, 'oracle', '_build', 'hp_truth')
@@ -105,7 +108,8 @@ def main():
             save['err_%s_%s' % (name, tag)] = np.float64(rel(o['gstep'][key], part[tag]))
         print('[hp-large] float64 %-8s (%.0f s): ' % (linalg, time.time() - t0) +
               '  '.join('%s %.2e' % (k, save['err_%s_%s' % (name, k)]) for k in BLOCKS + ('Abar', 'Bbar', 'dFdK')))
-    out = os.path.join(HERE, 'hp_truth_large_N%d%s.npz' % (N, '' if (seed, z_seed) == (100, None) else '_s%d_z%d' % (seed, -1 if z_seed is None else z_seed)))
+    out = os.path.join(HERE, 'hp_truth_%s_N%d%s.npz' % ('large' if M == 512 else 'M%d' % M, N,
+                                                       '' if (seed, z_seed) == (100, None) else '_s%d_z%d' % (seed, -1 if z_seed is None else z_seed)))
     np.savez_compressed(out, **save)
     print('[hp-large] wrote', out, os.path.getsize(out), 'bytes;  scratch in', work)
 

@@ -134,3 +134,39 @@ def test_the_double_double_product_is_what_closes_the_gap():
     print('draw (102, 12), N = 1e5: grad_Z vs truth  float64 product %.2e   double-double product %.2e' % (plain, dd))
     assert plain > 5e-6 and dd <= 5e-7 and dd < plain / 10
     assert lib.gp_debug_set_option(b'no_such_option', 1) == _lib.GP_ERR_BAD_ARG
+
+
+@pytest.mark.gpu
+def test_global_step_products_on_the_int8_matrix_core_at_M_1024():
+    """csrc/gsi8.hip (round 5): from M = 1024 on, the global step's two double-double products -- K_mm^-1 Psi2 and the residual of the refinement step --
+    run as ten-digit exact products on the int8 matrix core.  The benchmark's generator at N = 5e4, D = 100, M = 1024, Q = 10: cond(K_mm + beta Psi2) =
+    5.6e11, where the float64 Cholesky port is 7.5e-4 and the reference's LU arrangement 1.8e-3 from the 80-bit truth on grad_Z and the truth's own
+    uncertainty is 8.5e-7 (tests/golden/make_hp_truth_large.py 50000 100 -1 1024).  Both device paths must stay within the contract of the truth, and the
+    int8 path must be as close to it as the double-double path it replaces."""
+    from gparml_amd import _lib
+    from gparml_amd.engine import ShardEngine
+    z = np.load(os.path.join(GOLDEN_DIR, 'hp_truth_M1024_N50000.npz'))
+    d, (N, D, M, Q) = _inputs(z)
+    assert M == 1024
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+    lib = _lib.load()
+    rep = {}
+    try:
+        for tag, on in (('int8', 1), ('double-double', 0)):
+            assert lib.gp_debug_set_option(b'gs_i8', on) == 0
+            out = eng.evaluate(False)
+            rep[tag] = {k: _err(out[k], z['truth_' + k]) for k in BLOCKS}
+            rep[tag]['F'] = abs(out['F'] - float(z['truth_F'])) / abs(float(z['truth_F']))
+    finally:
+        assert lib.gp_debug_set_option(b'gs_i8', 1) == 0
+    eng.close()
+    unc = float(z['truth_uncertainty'][1])
+    print('M = 1024, N = 5e4, cond %.1e: error vs the 80-bit truth (its own uncertainty on grad_Z %.1e; float64 Cholesky %.1e, LU %.1e):' % (
+        float(z['cond_A']), unc, float(z['err_chol_grad_Z']), float(z['err_lu_grad_Z'])), {t: {k: '%.1e' % v for k, v in r.items()} for t, r in rep.items()})
+    for tag in rep:
+        assert rep[tag]['F'] <= 1e-9
+        for k in BLOCKS:
+            assert rep[tag][k] <= 1e-5, (tag, k, rep[tag][k])
+    assert rep['int8']['grad_Z'] <= 2.0 * rep['double-double']['grad_Z'] + 2.0 * unc

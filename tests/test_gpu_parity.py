@@ -119,6 +119,9 @@ FIXED_SHAPES = [s for s in SHAPES if s[4] == 'A'] + [(1500, 6, 200, 11, 'A', 0.2
                                                      (500, 3, 40, 24, 'A', 0.1), (3000, 40, 300, 6, 'A', 1.0), (2500, 33, 1100, 9, 'A', 2.0),
                                                      (900, 104, 129, 5, 'A', 0.6), (900, 105, 129, 5, 'A', 0.6), (2000, 8, 1500, 10, 'A', 2.0),
                                                      (1300, 32, 256, 8, 'A', 0.8),
+                                                     # 13 and 16 panels of 128 (r05): the inverse factor by halves with pairs cut off at every level, the split-k plans of the
+                                                     # 128-tile kernel, the global step's int8 products (csrc/gsi8.hip: 1024 <= M <= 2048) at their upper end
+                                                     (1700, 5, 1537, 7, 'A', 2.0), (2100, 6, 2048, 8, 'A', 2.0),
                                                      # wide latent spaces: p2_gen8_kernel<false> on the features [mu | 1 | mu^2] (no m-contraction, no point kernel)
                                                      (700, 7, 150, 30, 'A', 0.05), (900, 104, 129, 50, 'A', 0.03), (400, 3, 300, 63, 'A', 0.03),
                                                      (1000, 12, 64, 25, 'A', 0.06)]

@@ -767,7 +767,8 @@ int run_global_step(gp_ctx* c) {
   // (measured, r03: 0.424 -> 0.455 ms at M = 512 and 0.12 -> 0.15 ms at M = 128 with the side stream on -- every cross-stream event edge costs
   // more than the 5-12 us product it hides; kept behind GPARML_GLOBAL_TWO_STREAMS=1 for the record, off by default)
   static const bool two_env = [] { const char* e = getenv("GPARML_GLOBAL_TWO_STREAMS"); return e && e[0] == '1'; }();
-  const bool two = two_env && (long)(Mp / TILE) * (std::max(Mp, Dp) / TILE) <= 256;
+  // (not with the int8 products: both use the context's one digit workspace, and T1 / the split-k workspace are shared as well from M = 1024 on)
+  const bool two = two_env && (long)(Mp / TILE) * (std::max(Mp, Dp) / TILE) <= 256 && !gi8 && Mp < 1024;
   if (two && !c->side) {
     GP_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) GP_HIP(c, hipEventCreateWithFlags(&c->gev[i], hipEventDisableTiming));

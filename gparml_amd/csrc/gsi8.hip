@@ -16,7 +16,9 @@
 //     planes[digit][k / 16][column][16 bytes]   -- the 16 consecutive k a lane feeds as ONE operand register quad
 // (A = K_mm^-1 and A = K_mm + beta Psi2 are symmetric, so "column i of W" is row i of A).  One wave owns a 32 x 32 output tile and loads its operands
 // straight from global memory in operand order (512-byte runs; the whole problem sits in L2), the next k-step's 20 loads in flight under the 55 MFMAs of
-// the current one; four waves per workgroup, one workgroup per CU (160 accumulator + 160 operand registers: AccVGPRs at one wave per SIMD).
+// the current one; four waves per workgroup, one workgroup per CU (160 accumulator + 160 operand registers: AccVGPRs at one wave per SIMD).  What bounds it at
+// M = 1024 is L2 bandwidth: 1024 tiles x 32 k-steps x 20 KB = 655 MB of operands per product in 58 us = 11 TB/s (a second k-step of look-ahead spilled and
+// could not have helped); sharing operands between the four waves of a workgroup through LDS would halve that -- not built, the product is 4 % of the step.
 #include "gp_common.h"
 #include <atomic>
 #include <cstdlib>

@@ -117,7 +117,7 @@ template <int QP, bool FIXA, int SL = 0, bool K2 = false>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                    long N, long Np, int M, int Mp, int Q, long ld, int WC, const double* __restrict__ alpha,
                                                    double lnsf2, int nblk, int8_t* __restrict__ Sl = nullptr, long strideJ = 0, double hscale = 0.0,
-                                                   double* __restrict__ Dpart = nullptr, int8_t* __restrict__ SlK = nullptr, long strideK = 0, int KS2 = 0) {
+                                                   double* __restrict__ Dpart = nullptr, int8_t* __restrict__ SlK = nullptr, long strideK = 0, int KS2 = 0, int temporal = 0) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
   // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
   // [mu | u | lnc1] records are staged in LDS (below).
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   // (4 / WC)-th row of a 16-row group instead of idling: M = 128 ran at a quarter of the rate)
   const int RG = 4 / WC, rg = wave / WC;
   const int col = (blockIdx.x * WC + (wave % WC)) * 128 + 2 * lane;
-  const long row0 = blockIdx.y * (long)PSI1_ROWS * nblk;      // nblk granules per workgroup: the per-lane set-up (z, sqrt(alpha)) is paid once
+  const long row0 = blockIdx.y * 16L * nblk;      // nblk = 16-row groups per workgroup (8 per 128-row granule): the per-lane set-up (z, sqrt(alpha)) is paid once
   const bool ok0 = col < M, ok1 = col + 1 < M;
   const ExpTab xt = exp_tab_lane();
   double z0[QP], z1[QP];
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   // travel while the current group is computed.  (Per-row scalar loads cost a serial memory round trip per row and held the
   // kernel at 1.9 ms although plain stores reach 5.5 TB/s: tools/ubench/store_ubench.hip.)
   constexpr int GR = 16, RPT = (GR * WS + 255) / 256;
-  const int NG = (int)min((long)nblk * (PSI1_ROWS / GR), (Np - row0) / GR);   // Np is a multiple of 128: whole groups only
+  const int NG = (int)min((long)nblk, (Np - row0) / GR);   // Np is a multiple of 128: whole groups only
   __shared__ double rec_s[2][GR * WS];
   // SL > 0: the second digit layout's transposition buffer, per wave [digit 7][16-column block 8][row 8][column pair 8] byte pairs (28 KB)
   __shared__ __attribute__((aligned(16))) unsigned short k2s[K2 ? 4 : 1][K2 ? 7 : 1][K2 ? 8 : 1][8][8];
@@ -307,7 +307,11 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       // non-temporal (one global_store_dwordx4 ... nt per lane): the 4.1 GB of Psi1 is next read after the whole array has been written,
       // so keeping it in L2 / MALL only evicts what the statistics kernels are about to use -- same-box A/B (three rounds): this kernel
       // 0.912 -> 0.932 ms, but p1v2_kernel 5.860 -> 5.795 and p2_fast8_kernel 10.051 -> 9.995 ms: evaluation 17.457 -> 17.354 ms
-      if (col < Mp) { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
+      // ... on a SHORT shard (temporal: [Psi1 | Y] <= 200 MB) plain stores: 50.6 -> 45.3 us at N = 1e5, M = 128 on one box (the kernels behind it do not change)
+      if (col < Mp) {
+        if (temporal) *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
+        else { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
+      }
     }
     }
     if (g + 1 < NG) {
@@ -539,8 +543,13 @@ int run_upload_y(gp_ctx* c, const double* dY) {
 template <int QP>
 static void launch_psi1(gp_ctx* c, bool fixa) {
   const int WC = c->Mp >= 512 ? 4 : (c->Mp >= 256 ? 2 : 1);
-  const int nblk = c->Np >= (1L << 17) ? 4 : 1;                  // 512 rows per workgroup on large shards (still >= 7 workgroups per CU at N = 1e6)
-  dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)((c->Np / PSI1_ROWS + nblk - 1) / nblk));
+  // 16-row groups per workgroup: 512 rows on large shards (still >= 7 workgroups per CU at N = 1e6), 128 rows below 2^17 rows (64-row workgroups on
+  // configs[1]'s 1e5 x 128 shard -- every workgroup resident at once -- changed nothing: 43-44 us, r05)
+  const int ngrp = c->Np >= (1L << 17) ? 32 : 8;
+  const int nblk = ngrp;
+  static const int temporal_env = [] { const char* e = getenv("GPARML_PSI1_TEMPORAL"); return e ? atoi(e) : -1; }();
+  const int temporal = temporal_env >= 0 ? temporal_env : ((size_t)c->Np * c->LDK * sizeof(double) <= ((size_t)200 << 20) ? 1 : 0);
+  dim3 grid((c->Mp + 128 * WC - 1) / (128 * WC), (unsigned)((c->Np / 16 + ngrp - 1) / ngrp));
   if constexpr (QP <= 16) if (fixa && WC == 4 && c->i8_active) {
     // int8 phase 1 (p1i8.hip): Psi1's digits are written next to Psi1 itself
     int8_t* Sl = nullptr; long strideJ = 0; double* Dpart = nullptr;
@@ -560,10 +569,10 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
   }
   if (fixa)
     hipLaunchKernelGGL((psi1_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                       (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk);
+                       (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, nullptr, 0L, 0.0, nullptr, nullptr, 0L, 0, temporal);
   else
     hipLaunchKernelGGL((psi1_kernel<QP, false>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                       (long)c->LDK, WC, (const double*)c->alpha, 0.0, nblk);
+                       (long)c->LDK, WC, (const double*)c->alpha, 0.0, nblk, nullptr, 0L, 0.0, nullptr, nullptr, 0L, 0, temporal);
 }
 
 template <int QP>

@@ -113,11 +113,11 @@ constexpr int PSI1_ROWS = 128;   // row granule of psi1_kernel (Np is a multiple
 // kernels are skipped from the second evaluation on).
 // SL > 0 (int8 phase 1, p1i8.hip; only the WC = 4 form, where a wave walks all 16 rows of a group): the element is also written as SL signed
 // 7-bit digits of t = Psi1 / (2 sf2) in (0, 1/2], sixteen consecutive rows packed into one 16-byte store per column and digit.
-template <int QP, bool FIXA, int SL = 0, bool K2 = false>
+template <int QP, bool FIXA, int SL = 0, bool K2 = false, bool TEMPORAL = false>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                    long N, long Np, int M, int Mp, int Q, long ld, int WC, const double* __restrict__ alpha,
                                                    double lnsf2, int nblk, int8_t* __restrict__ Sl = nullptr, long strideJ = 0, double hscale = 0.0,
-                                                   double* __restrict__ Dpart = nullptr, int8_t* __restrict__ SlK = nullptr, long strideK = 0, int KS2 = 0, int temporal = 0) {
+                                                   double* __restrict__ Dpart = nullptr, int8_t* __restrict__ SlK = nullptr, long strideK = 0, int KS2 = 0) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
   // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
   // [mu | u | lnc1] records are staged in LDS (below).
@@ -308,8 +308,9 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       // so keeping it in L2 / MALL only evicts what the statistics kernels are about to use -- same-box A/B (three rounds): this kernel
       // 0.912 -> 0.932 ms, but p1v2_kernel 5.860 -> 5.795 and p2_fast8_kernel 10.051 -> 9.995 ms: evaluation 17.457 -> 17.354 ms
       // ... on a SHORT shard (temporal: [Psi1 | Y] <= 200 MB) plain stores: 50.6 -> 45.3 us at N = 1e5, M = 128 on one box (the kernels behind it do not change)
+      // (a compile-time switch: as a run-time branch it broke the merge of the two non-temporal stores into one 16-byte store -- 0.96 -> 2.28 ms at N = 1e6)
       if (col < Mp) {
-        if (temporal) *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
+        if constexpr (TEMPORAL) *reinterpret_cast<double2*>(&Kaug[n * ld + col]) = v;
         else { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
       }
     }
@@ -568,11 +569,17 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
     c->i8_active = false;
   }
   if (fixa)
-    hipLaunchKernelGGL((psi1_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                       (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, nullptr, 0L, 0.0, nullptr, nullptr, 0L, 0, temporal);
+  {
+    if (temporal)
+      hipLaunchKernelGGL((psi1_kernel<QP, true, 0, false, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                         (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk);
+    else
+      hipLaunchKernelGGL((psi1_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                         (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk);
+  }
   else
     hipLaunchKernelGGL((psi1_kernel<QP, false>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                       (long)c->LDK, WC, (const double*)c->alpha, 0.0, nblk, nullptr, 0L, 0.0, nullptr, nullptr, 0L, 0, temporal);
+                       (long)c->LDK, WC, (const double*)c->alpha, 0.0, nblk);
 }
 
 template <int QP>

@@ -134,17 +134,15 @@ INT8_PEAK_TOPS = 4880.0    # v_mfma_i32_32x32x32_i8, sustained for 190 ms on thi
 def int8_variants(eng, d, N, D, M, Q, seed, steps=10):
     """The same workload on the opt-in int8 paths, timed OUTSIDE the headline region and priced against the int8 matrix core's own peak (the headline
     stays on the float64 matrix core): phase 1 (csrc/p1i8.hip: six signed 7-bit digits per operand, 21 exact digit products, Psi2's diagonal from float64
-    sums of squares, guarded at run time -- gp_i8_status) and, experimental, phase 2 as well (csrc/p2i8.hip: seven digits, 28 products; correct, not
-    faster: profiles/r05_int8_phase2.txt).  Device ms per evaluation next to the float64 default of the same run and the distance of each variant's
+    sums of squares, guarded at run time -- gp_i8_status).  (A phase 2 on the int8 matrix core was built in round 5 -- parity-green, not faster:
+    profiles/r05_int8_phase2.txt -- and removed in round 6.)  Device ms per evaluation next to the float64 default of the same run and the distance of each variant's
     gradients from the extended-precision truth."""
     from gparml_amd import _lib
     lib = _lib.load()
     res = {}
     try:
-        for name, p1, p2 in (('float64 (default: p1v2_kernel, p2_fast8_kernel)', 0, 0), ('int8 phase 1 (p1i8_kernel)', 1, 0),
-                             ('int8 phases 1 + 2 (p1i8_kernel, p2i8_kernel; experimental)', 1, 1)):
+        for name, p1 in (('float64 (default: p1v2_kernel, p2_fast8_kernel)', 0), ('int8 phase 1 (p1i8_kernel)', 1)):
             lib.gp_debug_set_option(b'p1_i8', p1)
-            lib.gp_debug_set_option(b'p2_i8', p2)
             eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'], N_global=N)
             tot = {}
             for i in range(steps + 3):            # the first int8 evaluation is the guard's check (both phase-1 paths): not in the average
@@ -162,14 +160,9 @@ def int8_variants(eng, d, N, D, M, Q, seed, steps=10):
                 ach = ops / (tot['p1_kernel_ms'] * 1e-3) / 1e12
                 r['roofline'] = {'bound': 'mfma', 'kernel': 'gp::p1i8_kernel', 'achieved': ach, 'peak': INT8_PEAK_TOPS, 'unit': 'TOP/s (int8)', 'frac': ach / INT8_PEAK_TOPS}
                 r['guard'] = eng.i8_status()
-            if p2:
-                ops2 = 2.0 * 28.0 * float(N) * M * (M + D)
-                ach2 = ops2 / (tot['p2_kernel_ms'] * 1e-3) / 1e12
-                r['roofline_phase2'] = {'bound': 'mfma', 'kernel': 'gp::p2i8_kernel', 'achieved': ach2, 'peak': INT8_PEAK_TOPS, 'unit': 'TOP/s (int8)', 'frac': ach2 / INT8_PEAK_TOPS}
             res[name] = r
     finally:
         lib.gp_debug_set_option(b'p1_i8', 0)
-        lib.gp_debug_set_option(b'p2_i8', 0)
     return res
 
 

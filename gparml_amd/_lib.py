@@ -69,6 +69,8 @@ SIGNATURES = {
     'gp_debug_gemm': (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_double, _dp, _dp, ctypes.c_double, _dp]),
     'gp_debug_set_option': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'gp_debug_potrf_inverse': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
+    'gp_debug_gemm_bench': (ctypes.c_int, [ctypes.c_int] * 7 + [_dp]),
+    'gp_debug_peek': (ctypes.c_int, [_vp, ctypes.c_char_p, _dp, ctypes.c_long]),
 }
 
 _lib = None

@@ -18,11 +18,17 @@ int fail(gp_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-template <typename T>
-static int dalloc(gp_ctx* c, T** p, size_t count) {
-  GP_HIP(c, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
-  GP_HIP(c, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
+std::atomic<int> g_opt_poison{[] { const char* e = getenv("GPARML_POISON"); return (e && e[0] == '1') ? 1 : 0; }()};
+int dalloc_bytes(gp_ctx* c, void** p, size_t bytes, int mode) {
+  bytes = std::max<size_t>(bytes, 8);
+  GP_HIP(c, hipMalloc(p, bytes));
+  const bool poison = g_opt_poison.load() && mode != DA_ZERO;
+  if (poison || mode != DA_RAW) GP_HIP(c, hipMemsetAsync(*p, poison ? 0xFF : 0, bytes, c->stream));
   return GP_OK;
+}
+template <typename T>
+static int dalloc(gp_ctx* c, T** p, size_t count, int mode = DA_INIT) {
+  return dalloc_bytes(c, (void**)p, count * sizeof(T), mode);
 }
 #define GP_TRY(x) do { int rc__ = (x); if (rc__ != GP_OK) return rc__; } while (0)
 
@@ -122,7 +128,9 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   auto A = [&](auto** p, size_t n) { if (rc == GP_OK) rc = dalloc(c, p, n); };
   A(&c->Kaug, (size_t)Np * c->LDK);
   A(&c->Xmu, (size_t)N_s * Q); A(&c->Xs, (size_t)N_s * Q); A(&c->dir, (size_t)2 * N_s * Q);
-  A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->U, (size_t)Np * Q); A(&c->PU, (size_t)Np * (2 * std::max(psi1_qp(Q), 2) + 2)); A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
+  A(&c->mu, (size_t)Np * Q); A(&c->S, (size_t)Np * Q); A(&c->U, (size_t)Np * Q);
+  if (rc == GP_OK) rc = dalloc(c, &c->PU, (size_t)Np * (2 * std::max(psi1_qp(Q), 2) + 2), DA_ZERO);   // zero contract: the records' columns Q .. QP - 1 (u = 0: no guards in psi1_kernel's q loop) are never written
+  A(&c->lnc1, (size_t)Np); A(&c->Xa, (size_t)Np * c->CXp);
   A(&c->Z, (size_t)Mp * Q); A(&c->alpha, (size_t)Q); A(&c->Zaug, (size_t)Mp * c->CZp + 8); A(&c->Zt, (size_t)Mp * Q);   // + 8: p2_gen8_kernel stages feature columns in groups of eight
   A(&c->stats, (size_t)Mp * Mp + Mp * Dp + SC_COUNT);
   A(&c->grads, (size_t)M * Q + Q);
@@ -144,7 +152,8 @@ extern "C" int gp_create(gp_ctx** out, int device, int64_t N_s, int D, int M, in
   A(&c->part, c->part_doubles);
   c->kl_blocks = blocks_for(Np);
   A(&c->klpart, (size_t)c->kl_blocks + 8192);
-  A(&c->Kmm, (size_t)2 * Mp * Mp); A(&c->Lmat, (size_t)2 * Mp * Mp); A(&c->Linv, (size_t)2 * Mp * Mp); A(&c->Inv, (size_t)2 * Mp * Mp);
+  A(&c->Kmm, (size_t)2 * Mp * Mp); A(&c->Lmat, (size_t)2 * Mp * Mp); A(&c->Inv, (size_t)2 * Mp * Mp);
+  if (rc == GP_OK) rc = dalloc(c, &c->Linv, (size_t)2 * Mp * Mp, DA_ZERO);   // zero contract: the 128-blocks above the block diagonal are never written (potrf_inverse_batched's precondition)
   if (Mp >= 512 && Mp <= 2048) {
     // gsi8.hip: ten digit planes of W = [A | B] for the larger of the two products (K_mm^-1 | Psi2: 2 Mp columns; K_mm + beta Psi2 | E: Mp + Dp), and W's column scales
     c->gss_count = (size_t)Mp + std::max(Mp, Dp);
@@ -184,7 +193,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
                     c->HZp, c->gXmu, c->gXs, c->gapart, c->hgpart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
-                    c->Gpart, c->Gtmp, c->gapart2, c->pp, c->Z1S, c->ppt, c->Gt, c->spack};
+                    c->Gpart, c->Gtmp, c->gapart2, c->pp, c->Z1S, c->ppt, c->Gt, c->spack, c->gen_T, c->gen_rt};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);
   if (c->ptiles) (void)hipFree(c->ptiles);
@@ -194,11 +203,8 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (c->staging) (void)hipFree(c->staging);
   gp::p1v2_free(c);
   gp::p1i8_free(c);
-  gp::p2i8_free(c);
   gp::comm_free(c);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-  for (int i = 0; i < 4; ++i) if (c->gev[i]) (void)hipEventDestroy(c->gev[i]);
-  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->h_out) (void)hipHostFree(c->h_out);
   for (int i = 0; i < 2; ++i) { if (c->h_glob[i]) (void)hipHostFree(c->h_glob[i]); if (c->glob_ev[i]) (void)hipEventDestroy(c->glob_ev[i]); }
   delete c;
@@ -294,7 +300,6 @@ extern "C" int gp_upload_shard(gp_ctx* c, const double* Y, const double* X_mu, c
   c->have_dir = false;
   c->prep_fixa_valid = false;
   c->i8_y_valid = false;
-  c->p2i8_y_valid = false;
   c->i8_guard = 0; c->i8_since_check = 0; c->i8_check_pending = false;      // new data: the int8 path is measured again (p1i8.hip, guard)
   return GP_OK;
 }
@@ -318,6 +323,37 @@ extern "C" int gp_set_direction(gp_ctx* c, const double* d) {
   return GP_OK;
 }
 
+// Test mode (gp_common.h, g_opt_poison): everything an evaluation is supposed to (re)write before it reads is refilled with NaN bytes when a new
+// evaluation starts -- scratch and partial sums, the statistics, the global step's matrices, the gradients, Psi1 (not Y), the regime-B tables.
+// Not refilled: the shard's data and what the prep kernels derive from it alone (they are skipped from the second evaluation on for fixed
+// embeddings), the CG vectors, Linv (its upper blocks are a zero contract), tables and plans.
+static int poison_scratch(gp_ctx* c) {
+  const size_t Mp = c->Mp, Dp = c->Dp, Np = c->Np, M = c->M, Q = c->Q, N = c->N;
+  auto P = [&](void* p, size_t bytes) -> hipError_t { return (p && bytes) ? hipMemsetAsync(p, 0xFF, bytes, c->stream) : hipSuccess; };
+  auto PD = [&](double* p, size_t n) -> hipError_t { return P(p, n * sizeof(double)); };
+  GP_HIP(c, PD(c->part, c->part_doubles));
+  GP_HIP(c, PD(c->Rpart, (size_t)2 * (c->p2_slices + 8) * Mp * c->CXp));
+  GP_HIP(c, PD(c->HZp, (size_t)(Mp / TILE) * Np * c->CZp));
+  GP_HIP(c, PD(c->gapart, (size_t)c->ga_blocks * Q));
+  GP_HIP(c, PD(c->hgpart, std::max((size_t)((N + 255) / 256) * Q, (size_t)8 * (c->p2_slices + 8) * (Mp / TILE) * 8 * 12)));
+  GP_HIP(c, PD(c->Kmm, 2 * Mp * Mp)); GP_HIP(c, PD(c->Lmat, 2 * Mp * Mp)); GP_HIP(c, PD(c->Inv, 2 * Mp * Mp)); GP_HIP(c, PD(c->KmmKeep, Mp * Mp));
+  GP_HIP(c, PD(c->T1, Mp * std::max<size_t>(std::max(Mp, Dp), 256))); GP_HIP(c, PD(c->T2, Mp * std::max(Mp, Dp)));
+  GP_HIP(c, PD(c->dFdK, Mp * Mp)); GP_HIP(c, PD(c->Bbar, Mp * Mp)); GP_HIP(c, PD(c->E, Mp * Dp)); GP_HIP(c, PD(c->PsiE, Mp * Dp)); GP_HIP(c, PD(c->Abar, Mp * Dp));
+  GP_HIP(c, PD(c->Bm, (size_t)c->LDK * Mp)); GP_HIP(c, PD(c->gK, M * Q + Q)); GP_HIP(c, PD(c->gs, (size_t)GS_COUNT + 8 + 8 * 64));
+  if (!c->stats_external) GP_HIP(c, PD(c->stats, Mp * Mp + Mp * Dp + SC_COUNT));
+  if (!c->grads_external) GP_HIP(c, PD(c->grads, M * Q + Q));
+  GP_HIP(c, PD(c->gXmu, N * Q)); GP_HIP(c, PD(c->gXs, N * Q));
+  GP_HIP(c, hipMemset2DAsync(c->Kaug, (size_t)c->LDK * 8, 0xFF, Mp * 8, Np, c->stream));      // the Psi1 columns of [Psi1 | Y]
+  if (c->b_alloc) {
+    GP_HIP(c, PD(c->LE, Np * Mp)); GP_HIP(c, PD(c->LET, Np * Mp));
+    GP_HIP(c, PD(c->Gpart, (size_t)c->pb_blocks * M * Q)); GP_HIP(c, PD(c->gapart2, (size_t)c->pb_blocks * Q)); GP_HIP(c, PD(c->Gtmp, (size_t)64 * M * Q));
+    GP_HIP(c, PD(c->pp, c->pp_doubles));
+    if (c->ppt) GP_HIP(c, PD(c->ppt, (size_t)c->n_tiles64 * (3 * Q + 1) * c->b_ch));
+    if (c->Gt) GP_HIP(c, PD(c->Gt, (size_t)c->b_S * c->n_tiles64 * 2 * 64 * Q));
+  }
+  return GP_OK;
+}
+
 extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const double* alpha, double beta, int64_t N_global, double step) {
   if (!c) return GP_ERR_BAD_ARG;
   if (!Z || !alpha) return fail(c, GP_ERR_BAD_ARG, "gp_set_globals: NULL array");
@@ -330,6 +366,7 @@ extern "C" int gp_set_globals(gp_ctx* c, const double* Z, double sf2, const doub
   for (long i = 0; i < (long)c->M * c->Q; ++i) if (!std::isfinite(Z[i])) return fail(c, GP_ERR_NON_FINITE, "Z is not finite");
   if (N_global < c->N) return fail(c, GP_ERR_BAD_ARG, "N_global (%ld) smaller than the local shard (%ld)", (long)N_global, (long)c->N);
   GP_HIP(c, hipSetDevice(c->device));
+  if (g_opt_poison.load()) GP_TRY(poison_scratch(c));
   // stage through pinned memory: hipMemcpyAsync from pageable memory blocks the host until the copy has been staged AND used to be followed by a
   // stream synchronisation here (r03: every evaluation of an optimiser paid it).  r05: no copy command at all -- zaug_kernel reads the pinned
   // (mapped) slot itself; two copy commands cost ~25 us of stream time at configs[1]'s size (blit dispatches with idle gaps around them,
@@ -418,7 +455,7 @@ __global__ void __launch_bounds__(256) stats_unpack_kernel(const double* __restr
 static int64_t spack_doubles(const gp_ctx* c) { return (int64_t)c->M * (c->M + 1) / 2 + (int64_t)c->M * c->D + SC_COUNT; }
 static int ensure_spack(gp_ctx* c) {
   if (!c->spack) {
-    GP_HIP(c, hipMalloc((void**)&c->spack, (size_t)spack_doubles(c) * sizeof(double)));
+    GP_TRY(dalloc_bytes(c, (void**)&c->spack, (size_t)spack_doubles(c) * sizeof(double), DA_RAW));
     GP_HIP(c, hipMemsetAsync(c->spack, 0, (size_t)spack_doubles(c) * sizeof(double), c->stream));
   }
   return GP_OK;
@@ -496,7 +533,7 @@ extern "C" int gp_buffer_combine(gp_ctx* dst, const gp_ctx* src, int which, int 
     if (dst->staging_doubles < (size_t)n) {
       if (dst->staging) (void)hipFree(dst->staging);
       dst->staging = nullptr; dst->staging_doubles = 0;
-      GP_HIP(dst, hipMalloc((void**)&dst->staging, (size_t)n * 8));
+      GP_TRY(dalloc_bytes(dst, (void**)&dst->staging, (size_t)n * 8, DA_RAW));
       dst->staging_doubles = (size_t)n;
     }
     GP_HIP(dst, hipMemcpyPeerAsync(dst->staging, dst->device, from, src->device, (size_t)n * 8, dst->stream));
@@ -545,10 +582,21 @@ extern "C" int gp_global_step_jitter(gp_ctx* c, int jitter_mask) {
 
 extern "C" int gp_global_step(gp_ctx* c) { return gp_global_step_jitter(c, 0); }
 
+// The int8 guard's decision (p1i8.hip) for an evaluation that ran both phase-1 paths.  It needs P = (K_mm + beta Psi2)^-1 of a global step that SUCCEEDED:
+// a step that failed or asks for the jitter retry leaves P non-finite and would reject the int8 path for a reason that has nothing to do with its
+// accuracy -- the check then stays pending (guard 0: the next evaluation runs both paths again).  Called wherever an evaluation's global step is
+// known to be over: gp_finish, gp_global_status, gp_download of a global-step array.
+static int resolve_i8_check(gp_ctx* c) {
+  if (!c->i8_check_pending || c->state < 2) return GP_OK;
+  if (check_global(c) != GP_OK) return GP_OK;     // the caller reports that status itself
+  return p1i8_check_finish(c);
+}
+
 extern "C" int gp_global_status(gp_ctx* c, int* retry_mask) {
   if (!c) return GP_ERR_BAD_ARG;
   if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_global_status before gp_global_step");
   GP_HIP(c, hipSetDevice(c->device));
+  GP_TRY(resolve_i8_check(c));
   const int rc = check_global(c);
   if (retry_mask) *retry_mask = (rc == GP_RETRY_JITTER) ? c->retry_mask : 0;
   return rc;
@@ -609,8 +657,10 @@ extern "C" int gp_download(gp_ctx* c, int which, double* dst, int64_t n) {
   GP_HIP(c, hipSetDevice(c->device));
   const long M = c->M, Mp = c->Mp, D = c->D, Dp = c->Dp, N = c->N, Q = c->Q;
   if (c->state >= 2 && (which == GP_ARR_KMM_INV || which == GP_ARR_KMM_PLUS_OP_INV || which == GP_ARR_DF_DKMM || which == GP_ARR_DF_DPSI1TY ||
-                        which == GP_ARR_DF_DPSI2 || which == GP_ARR_SCALARS))
+                        which == GP_ARR_DF_DPSI2 || which == GP_ARR_SCALARS)) {
+    GP_TRY(resolve_i8_check(c));
     GP_TRY(check_global(c));
+  }
   switch (which) {
     case GP_ARR_PSI1: return download_matrix(c, c->Kaug, c->LDK, N, M, dst, n);
     case GP_ARR_PSI2_SUM: return download_matrix(c, c->stats, Mp, M, M, dst, n);
@@ -704,7 +754,7 @@ extern "C" int gp_finish(gp_ctx* c, double* F, double* grad_Z, double* grad_sf2,
   if (c->state < 2) return fail(c, GP_ERR_STATE, "gp_finish before gp_global_step");
   GP_HIP(c, hipSetDevice(c->device));
   const bool want_grads = grad_Z || grad_alpha;
-  if (c->i8_check_pending) GP_TRY(p1i8_check_finish(c));      // this evaluation ran both phase-1 paths: decide whether the context stays on int8
+  GP_TRY(resolve_i8_check(c));      // this evaluation ran both phase-1 paths: decide whether the context stays on int8 (only behind a successful global step)
   if (want_grads && c->state < 3) {
     GP_TRY(check_global(c));   // a failed global step is the more useful message
     return fail(c, GP_ERR_STATE, "gp_finish: gradients requested before gp_phase2");

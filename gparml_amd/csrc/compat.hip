@@ -136,10 +136,10 @@ int compat_build(gp_ctx* c, int which, double** out, long* count) {
   const bool needs_p2 = (which == GP_ARR_PSI2_POINTS || which == GP_ARR_DPSI2_DZ || which == GP_ARR_DPSI2_DALPHA);
   if (needs_p2 && N * M * M > (1L << 28)) return fail(c, GP_ERR_UNSUPPORTED, "per-point psi2 tensor (N,M,M) too large for compat mode (%ld doubles)", N * M * M);
   double* buf = nullptr;
-  GP_HIP(c, hipMalloc((void**)&buf, std::max<long>(n, 1) * 8));
+  GP_TRY_RC(dalloc_bytes(c, (void**)&buf, (size_t)std::max<long>(n, 1) * 8, DA_RAW));
   double* p2 = nullptr;
   if (needs_p2) {
-    if (which == GP_ARR_PSI2_POINTS) p2 = buf; else GP_HIP(c, hipMalloc((void**)&p2, N * M * M * 8));
+    if (which == GP_ARR_PSI2_POINTS) p2 = buf; else GP_TRY_RC(dalloc_bytes(c, (void**)&p2, (size_t)(N * M * M) * 8, DA_RAW));
     if (!c->regime_A) { const int rc = run_dz2(c); if (rc != GP_OK) return rc; }
     hipLaunchKernelGGL(psi2_points_kernel, dim3(grid_for(N * M * M)), dim3(256), 0, c->stream, c->Kaug, (long)c->LDK, c->LE, c->Mp, c->Vn, c->DZ2,
                        N, (int)M, (int)Q, c->regime_A ? 1 : 0, p2);
@@ -173,7 +173,7 @@ int compat_build(gp_ctx* c, int which, double** out, long* count) {
 using namespace gp;
 
 static int up(gp_ctx* c, const double* h, long n, double** d) {
-  GP_HIP(c, hipMalloc((void**)d, std::max<long>(n, 1) * 8));
+  GP_TRY_RC(dalloc_bytes(c, (void**)d, (size_t)std::max<long>(n, 1) * 8, DA_RAW));
   GP_HIP(c, hipMemcpyAsync(*d, h, n * 8, hipMemcpyHostToDevice, c->stream));
   return GP_OK;
 }
@@ -192,7 +192,7 @@ extern "C" int gp_grad_from_parts(gp_ctx* c, int which, const double* dF_dKmm, c
   if (rc == GP_OK) rc = up(c, dF_dPsi2, M * M, &C);
   if (rc == GP_OK) rc = up(c, dPsi2_dX, M * Q * M, &c3);
   const long no = which == 0 ? M * Q : Q;
-  if (rc == GP_OK && hipMalloc((void**)&o, no * 8) != hipSuccess) rc = fail(c, GP_ERR_HIP, "hipMalloc failed");
+  if (rc == GP_OK) rc = dalloc_bytes(c, (void**)&o, (size_t)no * 8, DA_RAW);
   if (rc == GP_OK) {
     if (which == 0) hipLaunchKernelGGL(gradz_parts_kernel, dim3((unsigned)((M * Q + 255) / 256)), dim3(256), 0, c->stream, A, a3, B, b3, C, c3, (int)M, (int)Q, (int)D, o);
     else hipLaunchKernelGGL(gradalpha_parts_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, A, a3, B, b3, C, c3, (int)M, (int)Q, (int)D, o);

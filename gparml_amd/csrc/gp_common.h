@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstdarg>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/gparml_hip.h"
@@ -108,10 +109,6 @@ struct gp_ctx {
   bool i8_active = false;     // this evaluation's phase 1 runs on the int8 matrix core (psi1_kernel wrote the digits)
   bool i8_y_valid = false;    // Y's digits are current (reset by gp_upload_shard)
   bool i8_unsupported = false;  // the int8 plan could not be built for this context (falls back to the float64 kernels)
-  void* p2i8plan = nullptr;     // int8 phase 2 (p2i8.hip): the column-contiguous digits of [K | Y], B's digits and scales; built on first use
-  bool p2i8_active = false;     // this evaluation: psi1_kernel wrote the second digit layout and phase 2 runs on the int8 matrix core
-  bool p2i8_y_valid = false;    // Y's digits in the second layout are current (reset by gp_upload_shard)
-  bool p2i8_unsupported = false;
   // the int8 path's run-time guard (p1i8.hip, "guard"): 0 = not checked since the last upload, 1 = accepted, 2 = rejected (float64 from then on)
   int i8_guard = 0;
   bool i8_check_pending = false;   // this evaluation ran both phase-1 paths: gp_finish reads the comparison and decides
@@ -165,7 +162,7 @@ struct gp_ctx {
   double* MUP = nullptr;      // [Np][QB]  mu_nq, zero-padded
   double* alphaP = nullptr;   // [QB]      alpha, zero-padded
   double* Z1P = nullptr;      // [Mp][QB]  Z with a column of ones at index Q (only meaningful when QB > Q)
-  bool b_mfma = false;        // regime-B phase 2 on the matrix core (Q >= 17)
+  bool b_mfma = false;        // regime-B phase 1 on the matrix core (psi2_pairs_mfma_kernel: latent tables 32 / 52 / 64 wide with a spare column)
   bool b_sym = false;         // regime-B phase 2 on tile pairs (psi2_sym_kernel: Q <= 10, 64 < M <= 1024)
   double* Z1S = nullptr;      // [Mp][RT]  [Z | 1 at index QB | 0], RT = QB + 1 rounded up to 4: B operand of the row-side MFMAs
   int* sym_sched = nullptr;   // [rounds][waves] tile of every wave in every round (I | J << 16, -1 idle)
@@ -178,6 +175,7 @@ struct gp_ctx {
   double* Gtmp = nullptr;     // [64][M][Q] second-level grad_Z partials
   double* gapart2 = nullptr;  // [pb_blocks][Q]
   double* pp = nullptr;       // [Np][3Q+1] per-point running sums sr, zr, z2r, zt of the psi2 rows kernel
+  size_t pp_doubles = 0;
   int pb_blocks = 0;
   int nslab = 0, ppb = 0;     // regime-B phase-2 pair kernel: 64-column slabs of M, points per workgroup
   int* ptiles = nullptr;      // upper-triangular 16x16 tile table for the psi2 pair kernel
@@ -190,13 +188,14 @@ struct gp_ctx {
   double* Gt = nullptr;       // [b_S][tiles][2][64][Q] grad_Z partials per workgroup
   long b_ch = 0;              // points per launch
   int b_S = 0;                // point slices per launch
+  // regime B beyond the compiled latent widths (psi2_generic.hip, Q >= 64): psi2_n of a chunk of points and its row contractions
+  double* gen_T = nullptr;    // [gen_P][M][M]
+  double* gen_rt = nullptr;   // [gen_P][M][Q + 1]
+  long gen_P = 0;             // points per chunk
   // CG vectors (resident): grad_latest/new/old (2,N,Q) each
   double* g_latest = nullptr;
   double* g_new = nullptr;
   double* g_old = nullptr;
-  // global step: a second stream for the product chain that does not depend on the other one (created on first use), fork / join events
-  hipStream_t side = nullptr;
-  hipEvent_t gev[4] = {nullptr, nullptr, nullptr, nullptr};
   // RCCL communicator of this context's rank (comm.hip; NULL until gp_comm_init)
   void* comm = nullptr;
   int comm_ranks = 0, comm_rank = -1;
@@ -219,6 +218,15 @@ struct gp_ctx {
 namespace gp {
 extern thread_local std::string g_create_error;
 int fail(gp_ctx* ctx, int code, const char* fmt, ...);
+// Test mode (GPARML_POISON=1 at load time or gp_debug_set_option("poison_alloc", 1)): every device allocation that does not carry a documented
+// zero-initialisation contract is filled with 0xFF bytes (a NaN as a double, -1 as an int) instead of zeros, and gp_set_globals refills the
+// per-evaluation scratch and output buffers with it: a kernel that reads a region this evaluation did not write, or that relies on zeros nobody
+// promised, then fails deterministically (NaN in the outputs) instead of once in a thousand runs.  DA_ZERO marks the buffers whose zeros ARE part of the
+// design (padding nobody writes; each such call site says which region that is), DA_INIT the ones that were zeroed for tidiness only, DA_RAW the
+// ones that are not initialised at all outside the test mode (every element is written before it is read).
+extern std::atomic<int> g_opt_poison;
+enum { DA_ZERO = 0, DA_INIT = 1, DA_RAW = 2 };
+int dalloc_bytes(gp_ctx* c, void** p, size_t bytes, int mode);
 
 // psi.hip
 int run_upload_y(gp_ctx* c, const double* dY);
@@ -235,12 +243,6 @@ int p1i8_check_begin(gp_ctx* c);      // after run_phase1_i8: keep the int8 stat
 int p1i8_check_compare(gp_ctx* c);    // after the float64 phase 1: norms of the difference (device)
 int p1i8_check_finish(gp_ctx* c);     // gp_finish, after the stream synchronisation of a checked evaluation: decide
 void p1i8_free(gp_ctx* c);
-// p2i8.hip (regime A phase 2 on the int8 matrix core; only together with the int8 phase 1)
-bool p2i8_wanted(const gp_ctx* c);
-int p2i8_prepare(gp_ctx* c, const double* yscale, int8_t** SlK, long* strideK, int* KS2);
-int run_phase2_i8(gp_ctx* c, const double* yscale, int* nparts);
-void p2i8_free(gp_ctx* c);
-const double* p1i8_yscale(const gp_ctx* c);     // Y's per-column digit scales (p1i8.hip plan)
 // p1v2.hip (regime A phase 1 without wasted tile slots)
 bool p1v2_applicable(const gp_ctx* c);
 int run_phase1_v2(gp_ctx* c);
@@ -251,6 +253,11 @@ int run_generate_b(gp_ctx* c);
 int run_phase1_b(gp_ctx* c);
 int run_phase2_b(gp_ctx* c);
 int run_dz2(gp_ctx* c);
+// psi2_generic.hip (regime B for Q >= 64: plain kernels, any Q)
+bool b_generic(const gp_ctx* c);
+int run_le_generic(gp_ctx* c);
+int run_phase1_b_generic(gp_ctx* c);
+int run_phase2_b_generic(gp_ctx* c);
 // psi2_tile.hip (regime B phase 2 on tile pairs)
 bool pt2_applicable(const gp_ctx* c, bool sym_available);
 int run_phase2_b_tiles(gp_ctx* c);

@@ -23,7 +23,6 @@ std::atomic<int> g_opt_dd_kipsi2{env_on("GPARML_DD_KIPSI2") ? 1 : 0};
 std::atomic<int> g_opt_refine_E{env_on("GPARML_REFINE_E") ? 1 : 0};
 extern std::atomic<int> g_opt_p1_i8;      // p1i8.hip
 extern std::atomic<int> g_opt_i8_guard_strict;
-extern std::atomic<int> g_opt_p2_i8;      // p2i8.hip
 extern std::atomic<int> g_opt_gs_i8;      // gsi8.hip
 
 // r05, the global step at M >= 1024 (each switchable for same-box A/B through gp_debug_set_option):
@@ -761,19 +760,9 @@ int run_global_step(gp_ctx* c) {
   if (rc != GP_OK) return rc;
   double* Ki = c->Inv;
   double* P = c->Inv + mm;
-  // E = P C ; PsiE = Psi2 E ; T1 = E E^T   and, independent of it,   T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki.
-  // Every launch here is a handful of 5-12 us products that leave most of the chip idle, so the second chain runs on a side stream (fork /
-  // join by events; the small-tile GEMM needs no shared workspace).  Larger problems (> 256 tiles: split-k through the shared workspace) stay serial.
-  // (measured, r03: 0.424 -> 0.455 ms at M = 512 and 0.12 -> 0.15 ms at M = 128 with the side stream on -- every cross-stream event edge costs
-  // more than the 5-12 us product it hides; kept behind GPARML_GLOBAL_TWO_STREAMS=1 for the record, off by default)
-  static const bool two_env = [] { const char* e = getenv("GPARML_GLOBAL_TWO_STREAMS"); return e && e[0] == '1'; }();
-  // (not with the int8 products: both use the context's one digit workspace, and T1 / the split-k workspace are shared as well from M = 1024 on)
-  const bool two = two_env && (long)(Mp / TILE) * (std::max(Mp, Dp) / TILE) <= 256 && !gi8 && Mp < 1024;
-  if (two && !c->side) {
-    GP_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    for (int i = 0; i < 4; ++i) GP_HIP(c, hipEventCreateWithFlags(&c->gev[i], hipEventDisableTiming));
-  }
-  hipStream_t s2 = two ? c->side : st;
+  // E = P C ; PsiE = Psi2 E ; T1 = E E^T   and, independent of it,   T2 = Ki Psi2 ; dFdK(tmp) = T2 Ki.   One stream: a side stream for the second
+  // chain was measured slower (r03: 0.424 -> 0.455 ms at M = 512 -- every cross-stream event edge costs more than the 5-12 us product it hides)
+  // and was removed in r06.
   GemmP g;
   g.K = Mp; g.alpha = 1.0; g.beta = 0.0; g.tri = 0; g.sA = g.sB = g.sC = 0;
   // the 128-tile kernel with split-k where that gives >= 256 workgroups (M >= 1024: 72-74 -> 63 us per product incl. the reduce at M = 1024; at M = 2048 the
@@ -785,7 +774,6 @@ int run_global_step(gp_ctx* c) {
   const int bigMM = (bigok && (long)(Mp / TILE) * (Mp / TILE) * spMM >= 256) ? 1 : 0;
   g.ws = ws;
   g.big = bigMD; g.splits = bigMD ? spMD : 1;
-  if (two) { GP_HIP(c, hipEventRecord(c->gev[0], st)); GP_HIP(c, hipStreamWaitEvent(s2, c->gev[0], 0)); }
   g.A = P; g.lda = Mp; g.B = C; g.ldb = Dp; g.C = c->E; g.ldc = Dp;
   launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Dp, 1, g);
   // one refinement step of E with a double-double residual (PsiE is free until the next product); GPARML_REFINE_E=0 turns it off
@@ -812,18 +800,17 @@ int run_global_step(gp_ctx* c) {
   // in profiles/r04_dd_variants.txt: +50 us at M = 512, +9 us at M = 128, +0.29 ms at M = 1024 over the float64 matrix-core product of r03, which
   // GPARML_DD_KIPSI2=0 or gp_debug_set_option("dd_kipsi2", 0) restores)
   if (g_opt_dd_kipsi2.load() && gi8) {
-    GP_TRY_RC(run_gs_i8_product(c, s2, Ki, (long)Mp, Mp, Psi2, (long)Mp, Mp, Mp, c->T2, (long)Mp, nullptr));
+    GP_TRY_RC(run_gs_i8_product(c, st, Ki, (long)Mp, Mp, Psi2, (long)Mp, Mp, Mp, c->T2, (long)Mp, nullptr));
   } else if (g_opt_dd_kipsi2.load()) {
-    hipLaunchKernelGGL((ddacc_gemm_kernel<2, 8>), dim3(Mp / 64, Mp / 8), dim3(256), 0, s2, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp);
+    hipLaunchKernelGGL((ddacc_gemm_kernel<2, 8>), dim3(Mp / 64, Mp / 8), dim3(256), 0, st, Ki, (long)Mp, Psi2, (long)Mp, Mp, c->T2, (long)Mp);
     GP_HIP(c, hipGetLastError());
   } else {
     g.K = Mp; g.big = bigMM; g.splits = bigMM ? spMM : 1; g.A = Ki; g.lda = Mp; g.B = Psi2; g.ldb = Mp; g.C = c->T2; g.ldc = Mp;
-    launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
+    launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   }
   g.K = Mp; g.big = bigMM; g.splits = bigMM ? spMM : 1;
   g.A = c->T2; g.lda = Mp; g.B = Ki; g.ldb = Mp; g.C = c->dFdK; g.ldc = Mp;
-  launch_gemm(s2, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
-  if (two) { GP_HIP(c, hipEventRecord(c->gev[1], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[1], 0)); }
+  launch_gemm(st, K_CONTIG, FREE_CONTIG, Mp, Mp, 1, g);
   GP_HIP(c, hipGetLastError());
   // dFdK currently holds Ki Psi2 Ki; assemble in place is unsafe (reads KPK, writes dFdK at the same index: fine, same thread)
   hipLaunchKernelGGL(assemble_kernel, dim3(1024), dim3(256), 0, st, Ki, P, c->T1, c->dFdK, c->E, c->beta, (double)D, Mp, Dp, c->Bbar,
@@ -840,19 +827,17 @@ int run_global_step(gp_ctx* c) {
   jobs.j[6] = {c->Bbar, Psi2, Mp, M, M, GS_SUM_BPSI2};
   double* dpart = c->gs + GS_COUNT + 8;   // [jobs][DOT_BLOCKS]
   // the traces / scalars and the Kmm parts of the gradients both start from the assembled partials and do not touch each other's outputs
-  if (two) { GP_HIP(c, hipEventRecord(c->gev[2], st)); GP_HIP(c, hipStreamWaitEvent(s2, c->gev[2], 0)); }
   hipLaunchKernelGGL(dots_kernel, dim3(DOT_BLOCKS, jobs.n), dim3(256), 0, st, jobs, dpart);
   hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(64), 0, st, sc, c->gs, jobs, dpart, c->beta, c->sf2, (double)D, (double)c->N_global);
   // Kmm parts of grad_Z / grad_alpha; alpha partials per row go through T2 (free again)
   static const bool kmm_lds = [] { const char* e = getenv("GPARML_KMM_LDS"); return !(e && e[0] == '0'); }();
   if (kmm_lds && M <= 2048)
-    hipLaunchKernelGGL(kmm_grads_lds_kernel, dim3(M), dim3(128), (size_t)2 * 128 * ((M + 127) / 128) * sizeof(double), s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z,
+    hipLaunchKernelGGL(kmm_grads_lds_kernel, dim3(M), dim3(128), (size_t)2 * 128 * ((M + 127) / 128) * sizeof(double), st, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z,
                        c->Zt, c->alpha, M, Mp, Q, c->regime_A ? 1 : 0, c->gK, c->T2);
   else
-    hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, s2, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
+    hipLaunchKernelGGL(kmm_grads_kernel, dim3(M), dim3(128), 0, st, c->dFdK, c->KmmKeep, c->Bbar, Psi2, c->Z, c->alpha, M, Mp, Q,
                        c->regime_A ? 1 : 0, c->gK, c->T2);
-  hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, s2, c->T2, M, Q, c->gK + (long)M * Q);
-  if (two) { GP_HIP(c, hipEventRecord(c->gev[3], s2)); GP_HIP(c, hipStreamWaitEvent(st, c->gev[3], 0)); }
+  hipLaunchKernelGGL(colsum_kernel, dim3(Q), dim3(256), 0, st, c->T2, M, Q, c->gK + (long)M * Q);
   GP_HIP(c, hipGetLastError());
   c->gs_pending = true;   // scalars and failure flags are read back at the next host synchronisation point (check_global)
   return GP_OK;
@@ -868,14 +853,14 @@ extern "C" int gp_debug_set_option(const char* name, int value) {
   if (!std::strcmp(name, "refine_E")) { g_opt_refine_E.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "p1_i8")) { g_opt_p1_i8.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "gs_tail")) { g_opt_gs_tail.store(value ? 1 : 0); return GP_OK; }
-  if (!std::strcmp(name, "p2_i8")) { g_opt_p2_i8.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "i8_guard_strict")) { g_opt_i8_guard_strict.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "xtx_tri")) { g_opt_xtx_tri.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "residual_dd")) { g_opt_residual_dd.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "gemm_big")) { g_opt_gemm_big.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "trtri_rec")) { g_opt_trtri_rec.store(value ? 1 : 0); return GP_OK; }
   if (!std::strcmp(name, "gs_i8")) { g_opt_gs_i8.store(value ? 1 : 0); return GP_OK; }
-  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, p2_i8, gs_tail, i8_guard_strict, xtx_tri, residual_dd, gemm_big, trtri_rec, gs_i8)", name);
+  if (!std::strcmp(name, "poison_alloc")) { g_opt_poison.store(value ? 1 : 0); return GP_OK; }
+  return fail(nullptr, GP_ERR_BAD_ARG, "gp_debug_set_option: unknown option '%s' (dd_kipsi2, refine_E, p1_i8, gs_tail, i8_guard_strict, xtx_tri, residual_dd, gemm_big, trtri_rec, gs_i8, poison_alloc)", name);
 }
 
 extern "C" int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet) {
@@ -929,6 +914,20 @@ extern "C" int gp_debug_peek(gp_ctx* c, const char* name, double* out, long n) {
   else if (!std::strcmp(name, "Bm")) { src = c->Bm; cnt = (long)c->LDK * c->Mp; }
   else if (!std::strcmp(name, "gK")) { src = c->gK; cnt = (long)c->M * c->Q + c->Q; }
   else if (!std::strcmp(name, "gs")) { src = c->gs; cnt = GS_COUNT + 8 + 8 * 64; }
+  // r06 (poison probe, tests/devtools/dev_poison_probe.py): the padded device images of the evaluation's other buffers
+  else if (!std::strcmp(name, "stats")) { src = c->stats; cnt = mm + md + SC_COUNT; }
+  else if (!std::strcmp(name, "Kaug")) { src = c->Kaug; cnt = (long)c->Np * c->LDK; }
+  else if (!std::strcmp(name, "Kmm")) { src = c->Kmm; cnt = 2 * mm; }
+  else if (!std::strcmp(name, "KmmKeep")) { src = c->KmmKeep; cnt = mm; }
+  else if (!std::strcmp(name, "Z")) { src = c->Z; cnt = (long)c->Mp * c->Q; }
+  else if (!std::strcmp(name, "Zaug")) { src = c->Zaug; cnt = (long)c->Mp * c->CZp; }
+  else if (!std::strcmp(name, "mu")) { src = c->mu; cnt = (long)c->Np * c->Q; }
+  else if (!std::strcmp(name, "S")) { src = c->S; cnt = (long)c->Np * c->Q; }
+  else if (!std::strcmp(name, "Xa")) { src = c->Xa; cnt = (long)c->Np * c->CXp; }
+  else if (!std::strcmp(name, "grads")) { src = c->grads; cnt = (long)c->M * c->Q + c->Q; }
+  else if (!std::strcmp(name, "Rpart")) { src = c->Rpart; cnt = (long)2 * (c->p2_slices + 8) * c->Mp * c->CXp; }
+  else if (!std::strcmp(name, "LE")) { src = c->LE; cnt = c->LE ? (long)c->Np * c->Mp : 0; }
+  else if (!std::strcmp(name, "LEA")) { src = c->LET; cnt = c->LET ? (long)c->Np * c->Mp : 0; }
   else return fail(c, GP_ERR_BAD_ARG, "gp_debug_peek: unknown buffer '%s'", name);
   if (n < cnt) return fail(c, GP_ERR_BAD_ARG, "gp_debug_peek: %ld doubles needed", cnt);
   GP_HIP(c, hipStreamSynchronize(c->stream));

@@ -302,12 +302,12 @@ int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ, double** Dpart, int row_
     Guard guard{c, pl};
     const int MT = c->Mp / TILE, DT = c->Dp / TILE;
     pl->strideJ = (c->Np / 16) * (long)c->LDK * 16;
-    GP_HIP(c, hipMalloc((void**)&pl->Sl, (size_t)I8S * pl->strideJ));
-    GP_HIP(c, hipMalloc((void**)&pl->yscale, (size_t)c->Dp * sizeof(double)));
-    GP_HIP(c, hipMalloc((void**)&pl->pmax, (size_t)1024 * c->Dp * sizeof(double)));
+    GP_TRY_RC(dalloc_bytes(c, (void**)&pl->Sl, (size_t)I8S * pl->strideJ, DA_RAW));
+    GP_TRY_RC(dalloc_bytes(c, (void**)&pl->yscale, (size_t)c->Dp * sizeof(double), DA_RAW));
+    GP_TRY_RC(dalloc_bytes(c, (void**)&pl->pmax, (size_t)1024 * c->Dp * sizeof(double), DA_RAW));
     pl->row_blocks = row_blocks;
-    GP_HIP(c, hipMalloc((void**)&pl->dpart, (size_t)row_blocks * c->Mp * sizeof(double)));
-    GP_HIP(c, hipMalloc((void**)&pl->diag, (size_t)c->Mp * sizeof(double)));
+    GP_TRY_RC(dalloc_bytes(c, (void**)&pl->dpart, (size_t)row_blocks * c->Mp * sizeof(double), DA_RAW));
+    GP_TRY_RC(dalloc_bytes(c, (void**)&pl->diag, (size_t)c->Mp * sizeof(double), DA_RAW));
     // tiles of one n-slice: Psi2 upper tiles, then the C tiles; slices per XCD chosen for whole rounds of the XCD's 32 CUs (one workgroup
     // per CU: 320 accumulator registers), every tile of a slice on ONE XCD so that the slice's digits are fetched from HBM once
     std::vector<int> tiles;                                 // (row block, column block) of 128 combined columns [Psi1 | Y]
@@ -383,11 +383,6 @@ int p1i8_prepare(gp_ctx* c, int8_t** Sl, long* strideJ, double** Dpart, int row_
   return GP_OK;
 }
 
-const double* p1i8_yscale(const gp_ctx* c) {
-  const I8Plan* pl = static_cast<const I8Plan*>(c->i8plan);
-  return pl ? pl->yscale : nullptr;
-}
-
 int run_phase1_i8(gp_ctx* c) {
   I8Plan* pl = static_cast<I8Plan*>(c->i8plan);
   if (!pl || !pl->y_valid) return fail(c, GP_ERR_STATE, "int8 phase 1 without its digit buffers (psi1 did not write them)");
@@ -454,7 +449,7 @@ __global__ void __launch_bounds__(256) i8_compare_final_kernel(double* __restric
 
 int p1i8_check_begin(gp_ctx* c) {
   const size_t n = (size_t)c->Mp * c->Mp + (size_t)c->Mp * c->Dp;
-  if (!c->i8_cmp) GP_HIP(c, hipMalloc((void**)&c->i8_cmp, (8 + 4 * I8_CMP_BLOCKS + n) * sizeof(double)));
+  if (!c->i8_cmp) GP_TRY_RC(dalloc_bytes(c, (void**)&c->i8_cmp, (8 + 4 * I8_CMP_BLOCKS + n) * sizeof(double), DA_RAW));
   // the int8 statistics aside (behind the comparison scalars): the float64 phase 1 overwrites the statistics buffer
   GP_HIP(c, hipMemcpyAsync(c->i8_cmp + 8 + 4 * I8_CMP_BLOCKS, c->stats, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return GP_OK;

@@ -113,11 +113,11 @@ constexpr int PSI1_ROWS = 128;   // row granule of psi1_kernel (Np is a multiple
 // kernels are skipped from the second evaluation on).
 // SL > 0 (int8 phase 1, p1i8.hip; only the WC = 4 form, where a wave walks all 16 rows of a group): the element is also written as SL signed
 // 7-bit digits of t = Psi1 / (2 sf2) in (0, 1/2], sixteen consecutive rows packed into one 16-byte store per column and digit.
-template <int QP, bool FIXA, int SL = 0, bool K2 = false, bool TEMPORAL = false>
+template <int QP, bool FIXA, int SL = 0, bool TEMPORAL = false>
 __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU, const double* __restrict__ Z, double* __restrict__ Kaug,
                                                    long N, long Np, int M, int Mp, int Q, long ld, int WC, const double* __restrict__ alpha,
                                                    double lnsf2, int nblk, int8_t* __restrict__ Sl = nullptr, long strideJ = 0, double hscale = 0.0,
-                                                   double* __restrict__ Dpart = nullptr, int8_t* __restrict__ SlK = nullptr, long strideK = 0, int KS2 = 0) {
+                                                   double* __restrict__ Dpart = nullptr) {
   // A workgroup writes 16 rows x 512 columns: wave w owns 128 columns (two adjacent per lane -> one 16-byte store per lane),
   // so a row's 4 KB leave the CU together (one DRAM page) instead of from four workgroups on four XCDs.  The rows' packed
   // [mu | u | lnc1] records are staged in LDS (below).
@@ -145,8 +145,6 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
   constexpr int GR = 16, RPT = (GR * WS + 255) / 256;
   const int NG = (int)min((long)nblk, (Np - row0) / GR);   // Np is a multiple of 128: whole groups only
   __shared__ double rec_s[2][GR * WS];
-  // SL > 0: the second digit layout's transposition buffer, per wave [digit 7][16-column block 8][row 8][column pair 8] byte pairs (28 KB)
-  __shared__ __attribute__((aligned(16))) unsigned short k2s[K2 ? 4 : 1][K2 ? 7 : 1][K2 ? 8 : 1][8][8];
   double stage[RPT];
   double dsq0 = 0.0, dsq1 = 0.0;            // SL > 0: sum of squares of the lane's two columns over this workgroup's rows (the exact diagonal of Psi2, p1i8.hip)
   auto fetch = [&](int g, int i) -> double {
@@ -166,20 +164,15 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
     }
     const double* recs = rec_s[g & 1];
     if constexpr (SL > 0) {
-      // all 16 rows of the group by this wave (RG = 1), unrolled: the digits of the two columns collect in 2 SL x 4 registers
-      // (two passes of eight rows -- not unrolled over the passes: the digit registers of sixteen rows, 2 x SL x 4, pushed the two-layout form to
-      // 256 VGPRs = one wave per SIMD)
-      constexpr int RP = K2 ? 8 : GR;        // rows per pass (the phase-1-only form keeps all sixteen rows of a group in one pass: one 16-byte store per digit)
-#pragma unroll 1
-      for (int r8 = 0; r8 < GR; r8 += RP) {
-      unsigned pk0[SL][RP / 4], pk1[SL][RP / 4];
+      // all 16 rows of the group by this wave (RG = 1), unrolled: the digits of the two columns collect in 2 SL x 4 registers, one 16-byte store
+      // per digit and column
+      unsigned pk0[SL][GR / 4], pk1[SL][GR / 4];
 #pragma unroll
       for (int j = 0; j < SL; ++j)
 #pragma unroll
-        for (int w = 0; w < RP / 4; ++w) { pk0[j][w] = 0u; pk1[j][w] = 0u; }
+        for (int w = 0; w < GR / 4; ++w) { pk0[j][w] = 0u; pk1[j][w] = 0u; }
 #pragma unroll
-      for (int rr8 = 0; rr8 < RP; ++rr8) {
-      const int r = r8 + rr8;
+      for (int r = 0; r < GR; ++r) {
       const long n = row0 + GR * g + r;       // Np is a multiple of 128: always in range
       const double* row = recs + r * WS;
       double e0 = 0.0, e1 = 0.0;
@@ -203,84 +196,27 @@ __global__ void __launch_bounds__(256) psi1_kernel(const double* __restrict__ PU
       // so keeping it in L2 / MALL only evicts what the statistics kernels are about to use -- same-box A/B (three rounds): this kernel
       // 0.912 -> 0.932 ms, but p1v2_kernel 5.860 -> 5.795 and p2_fast8_kernel 10.051 -> 9.995 ms: evaluation 17.457 -> 17.354 ms
       if (col < Mp) { __builtin_nontemporal_store(v.x, &Kaug[n * ld + col]); __builtin_nontemporal_store(v.y, &Kaug[n * ld + col + 1]); }
-        dsq0 = fma(v.x, v.x, dsq0); dsq1 = fma(v.y, v.y, dsq1);
-        if constexpr (!K2) {
-          // phase 1 only: SL rounds of multiply, round to nearest, subtract -- symmetric digits in [-64, 64], 1.62 ms at N = 1e6 against 2.05 ms for
-          // the integer extraction below (measured r05: its ~29 integer instructions per element cost more than these quarter-rate conversions)
-          double t0 = v.x * hscale, t1 = v.y * hscale;
+      dsq0 = fma(v.x, v.x, dsq0); dsq1 = fma(v.y, v.y, dsq1);
+      // SL rounds of multiply, round to nearest, subtract: symmetric digits in [-64, 64] (mean zero: the dropped tail does not bias the sums; digits
+      // cut from the bit fields of one integer lie in [-64, 63] and need a per-element offset hash for that -- r05, removed with the int8 phase 2)
+      double t0 = v.x * hscale, t1 = v.y * hscale;
 #pragma unroll
-          for (int j = 0; j < SL; ++j) {
-            t0 *= 128.0; t1 *= 128.0;
-            const double g0 = __builtin_rint(t0), g1 = __builtin_rint(t1);
-            t0 -= g0; t1 -= g1;
-            pk0[j][rr8 >> 2] |= ((unsigned)(int)g0 & 0xffu) << (8 * (rr8 & 3));
-            pk1[j][rr8 >> 2] |= ((unsigned)(int)g1 & 0xffu) << (8 * (rr8 & 3));
-          }
-        } else {
-          // Seven balanced base-128 digits of t = Psi1 / (2 sf2) in [0, 1/2] from ONE integer (r05; r04: six rounds of multiply, round, subtract,
-          // convert -- 33 VALU instructions per element, several of them quarter-rate): t + 12 has ulp 2^-49, so the low 51 bits of its mantissa are
-          // rint(t 2^49); adding C = 64 (1 + 128 + ... + 128^6) makes every 7-bit field f_k = d_k + 64 of the balanced representation
-          // sum_k d_k 128^k, d_k in [-64, 63] (the leading one in [0, 64]); digit j = 1 .. 7 (most significant first) is d_(7-j).  Phase 1 (p1i8.hip)
-          // takes the first SL = 6 of them in the 16-rows-per-operand layout, phase 2 (p2i8.hip) all seven in the 16-columns-per-operand layout.
-          constexpr unsigned long long DIGC = 64ull * ((1ull << 49) - 1ull) / 127ull, DIGT = ((1ull << 49) - 1ull) / 127ull;
-          // Digits from the fields of I + C lie in [-64, 63]: mean -1/2.  The digit phase 1 drops then biases every operand by -1/2 128^-7 and every
-          // entry of Psi2 with it, independently of N (measured: |dPsi2|_F / |Psi2|_F 8.6e-15 at N = 1e5 and 1e6, grad_Z 1.3e-7 from the truth, against
-          // 1.2e-15 / 4.0e-8 for the symmetric digits of round-to-nearest).  So half of the elements use the offset 63 instead of 64 -- fields of
-          // I + C - T, T = 1 + 128 + ... + 128^6, digits f_k - 63 in [-63, 64], mean +1/2 -- chosen by a hash of (row, column) that does not depend on
-          // the value: every digit has mean zero over the rows, for each column and each pair of columns.
-          const unsigned hrow = (unsigned)n * 0x9E3779B1u;
-          const unsigned sb0 = ((hrow + (unsigned)col * 0x85EBCA6Bu) * 0xC2B2AE35u) >> 31, sb1 = ((hrow + (unsigned)(col + 1) * 0x85EBCA6Bu) * 0xC2B2AE35u) >> 31;
-          const unsigned long long i0 = ((unsigned long long)__double_as_longlong(fma(v.x, hscale, 12.0)) & ((1ull << 51) - 1ull)) + (sb0 ? DIGC - DIGT : DIGC);
-          const unsigned long long i1 = ((unsigned long long)__double_as_longlong(fma(v.y, hscale, 12.0)) & ((1ull << 51) - 1ull)) + (sb1 ? DIGC - DIGT : DIGC);
-          const unsigned o0 = 64u - sb0, o1 = 64u - sb1;
-          // the fields from the two 32-bit halves (64-bit shifts are two quarter-rate instructions each): bits 0-27 from the low word, 28-34 across,
-          // 35-41 and the leading digit from the high word
-          const unsigned wl0 = (unsigned)i0, wh0 = (unsigned)(i0 >> 32), wl1 = (unsigned)i1, wh1 = (unsigned)(i1 >> 32);
-          unsigned f0[7], f1[7];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { f0[k] = __builtin_amdgcn_ubfe(wl0, 7 * k, 7); f1[k] = __builtin_amdgcn_ubfe(wl1, 7 * k, 7); }
-          f0[4] = __builtin_amdgcn_alignbit(wh0, wl0, 28) & 127u; f1[4] = __builtin_amdgcn_alignbit(wh1, wl1, 28) & 127u;
-          f0[5] = __builtin_amdgcn_ubfe(wh0, 3, 7); f1[5] = __builtin_amdgcn_ubfe(wh1, 3, 7);
-          f0[6] = wh0 >> 10; f1[6] = wh1 >> 10;
-#pragma unroll
-          for (int j = 0; j < 7; ++j) {
-            const unsigned b0 = (f0[6 - j] - o0) & 0xffu, b1 = (f1[6 - j] - o1) & 0xffu;
-            if (j < SL) {
-              pk0[j][rr8 >> 2] |= b0 << (8 * (rr8 & 3));
-              pk1[j][rr8 >> 2] |= b1 << (8 * (rr8 & 3));
-            }
-            if (K2) k2s[wave][j][lane >> 3][rr8][lane & 7] = (unsigned short)(b0 | (b1 << 8));
-          }
-        }
-        if (K2 && rr8 == 7) {
-          // eight rows of the wave's 128 columns sit in LDS as [digit][16-column block][row][16 B]: lane (block = lane >> 3, row = lane & 7) moves
-          // one 16-byte operand per digit to SlK[digit][n-tile][k-step][16-k half][row][16 B] (eight lanes = 128 contiguous bytes)
-          __builtin_amdgcn_wave_barrier();
-          const long nb = row0 + GR * g + r8;                        // first of the eight rows
-          const int cbi = (col - 2 * lane) / 16 + (lane >> 3);      // 16-column block of the combined [Psi1 | Y] columns
-          int8_t* dst2 = SlK + ((((nb >> 7) * KS2 + (cbi >> 1)) * 2 + (cbi & 1)) * 128 + ((nb & 127) + (lane & 7))) * 16;
-          if (col - 2 * lane + 16 * (lane >> 3) < Mp) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) *(uint4*)(dst2 + (long)j * strideK) = *(const uint4*)&k2s[wave][j][lane >> 3][lane & 7][0];
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
+      for (int j = 0; j < SL; ++j) {
+        t0 *= 128.0; t1 *= 128.0;
+        const double g0 = __builtin_rint(t0), g1 = __builtin_rint(t1);
+        t0 -= g0; t1 -= g1;
+        pk0[j][r >> 2] |= ((unsigned)(int)g0 & 0xffu) << (8 * (r & 3));
+        pk1[j][r >> 2] |= ((unsigned)(int)g1 & 0xffu) << (8 * (r & 3));
+      }
       }
       if (col < Mp) {
-        int8_t* dst = Sl + (((row0 + GR * g) / 16) * ld + col) * 16 + r8;       // rows r8 .. r8 + 7 of the 16-row operand
+        int8_t* dst = Sl + (((row0 + GR * g) / 16) * ld + col) * 16;
 #pragma unroll
         for (int j = 0; j < SL; ++j) {
-          if constexpr (RP == 16) {
-            uint4 a0 = {pk0[j][0], pk0[j][1], pk0[j][2], pk0[j][3]}, a1 = {pk1[j][0], pk1[j][1], pk1[j][2], pk1[j][3]};
-            *(uint4*)(dst + (long)j * strideJ) = a0;
-            *(uint4*)(dst + (long)j * strideJ + 16) = a1;
-          } else {
-            uint2 a0 = {pk0[j][0], pk0[j][1]}, a1 = {pk1[j][0], pk1[j][1]};
-            *(uint2*)(dst + (long)j * strideJ) = a0;
-            *(uint2*)(dst + (long)j * strideJ + 16) = a1;
-          }
+          uint4 a0 = {pk0[j][0], pk0[j][1], pk0[j][2], pk0[j][3]}, a1 = {pk1[j][0], pk1[j][1], pk1[j][2], pk1[j][3]};
+          *(uint4*)(dst + (long)j * strideJ) = a0;
+          *(uint4*)(dst + (long)j * strideJ + 16) = a1;
         }
-      }
       }
     } else {
 #pragma unroll 1
@@ -555,15 +491,8 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
     // int8 phase 1 (p1i8.hip): Psi1's digits are written next to Psi1 itself
     int8_t* Sl = nullptr; long strideJ = 0; double* Dpart = nullptr;
     if (p1i8_prepare(c, &Sl, &strideJ, &Dpart, (int)grid.y) == GP_OK) {
-      // int8 phase 2 (p2i8.hip, opt-in on top of the int8 phase 1): the same digits once more, sixteen consecutive COLUMNS per operand
-      int8_t* SlK = nullptr; long strideK = 0; int KS2 = 0;
-      c->p2i8_active = p2i8_wanted(c) && p2_fast_mode(c) && p2i8_prepare(c, p1i8_yscale(c), &SlK, &strideK, &KS2) == GP_OK;
-      if (c->p2i8_active)
-        hipLaunchKernelGGL((psi1_kernel<QP, true, GP_I8_DIGITS, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                           (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, Sl, strideJ, 0.5 / c->sf2, Dpart, SlK, strideK, KS2);
-      else
-        hipLaunchKernelGGL((psi1_kernel<QP, true, GP_I8_DIGITS>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
-                           (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, Sl, strideJ, 0.5 / c->sf2, Dpart);
+      hipLaunchKernelGGL((psi1_kernel<QP, true, GP_I8_DIGITS>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+                         (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk, Sl, strideJ, 0.5 / c->sf2, Dpart);
       return;
     }
     c->i8_active = false;
@@ -571,7 +500,7 @@ static void launch_psi1(gp_ctx* c, bool fixa) {
   if (fixa)
   {
     if (temporal)
-      hipLaunchKernelGGL((psi1_kernel<QP, true, 0, false, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
+      hipLaunchKernelGGL((psi1_kernel<QP, true, 0, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
                          (long)c->LDK, WC, (const double*)c->alpha, log(c->sf2), nblk);
     else
       hipLaunchKernelGGL((psi1_kernel<QP, true>), grid, dim3(256), 0, c->stream, c->PU, c->Z, c->Kaug, (long)c->N, (long)c->Np, c->M, c->Mp, c->Q,
@@ -611,7 +540,6 @@ int run_prep_and_generate(gp_ctx* c) {
     GP_HIP(c, hipGetLastError());
   }
   c->prep_fixa_valid = fixa;
-  c->p2i8_active = false;
   c->i8_active = fixa && p1i8_applicable(c);     // decided per evaluation (gp_debug_set_option("p1_i8", ...) switches it at run time)
   GP_EV(c, 8);
   const int QP = psi1_qp(c->Q);
@@ -1364,7 +1292,8 @@ __global__ void __launch_bounds__(256) point_kernel(PtArgs a) {
       const double quad = m * m * h - 2.0 * m * hzq + hz2;
       contrib[e] = -0.5 * (quad / (d1 * d1) + (s / d1) * h);
       a.gmu[n0 * a.Q + e] = -m - u * (m * h - hzq);
-      if (!a.regimeA) a.gS[n0 * a.Q + e] = -0.5 * (1.0 - 1.0 / s) + 0.5 * u * u * quad - 0.5 * u * h;
+      // (fixed variances S = 0: the reference's expression divides by S, partial_terms.py:400-431; the library defines the entry as 0 instead of leaving the buffer as it was)
+      a.gS[n0 * a.Q + e] = a.regimeA ? 0.0 : -0.5 * (1.0 - 1.0 / s) + 0.5 * u * u * quad - 0.5 * u * h;
     }
     __syncthreads();
     for (int q = t; q < a.Q; q += 256) {
@@ -1445,12 +1374,7 @@ int run_phase2(gp_ctx* c) {
     }
   }
 #endif
-  const bool p2i8 = fast && c->p2i8_active && !c->i8_check_pending;     // a guard evaluation (both phase-1 paths) keeps the float64 phase 2
-  int i8parts = 0;
-  if (p2i8) {
-    const int rc = run_phase2_i8(c, p1i8_yscale(c), &i8parts);
-    if (rc != GP_OK) return rc;
-  } else if (fast) {                                        // nrb <= 3
+  if (fast) {                                        // nrb <= 3
     p.gapart = c->hgpart;
     // (blocks past the last slice zero their own rows of hgpart)
     switch (nrb) {
@@ -1464,9 +1388,8 @@ int run_phase2(gp_ctx* c) {
   double* gZ = c->grads;
   double* ga = c->grads + (long)c->M * c->Q;
   // T2 is free after the global step: per-row alpha partials [M][Q]
-  // (int8 phase 2: eight partials per slice, feature columns [mu | 1 | mu^2] like the wide fixed-embedding form)
-  hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(256), 0, c->stream, c->Rpart, p2i8 ? i8parts : 2 * S, c->Mp, (fast && !p2i8) ? 4 * nrb : c->CXp, c->M, c->Q, c->Z,
-                     c->alpha, p2i8 ? 2 : (fast ? 1 : (widefix ? 2 : 0)), gZ, c->T2);
+  hipLaunchKernelGGL(p2_reduce_kernel, dim3(c->M), dim3(256), 0, c->stream, c->Rpart, 2 * S, c->Mp, fast ? 4 * nrb : c->CXp, c->M, c->Q, c->Z,
+                     c->alpha, fast ? 1 : (widefix ? 2 : 0), gZ, c->T2);
   GP_HIP(c, hipGetLastError());
   if (ppath) {
     PtArgs a;
@@ -1477,7 +1400,7 @@ int run_phase2(gp_ctx* c) {
     hipLaunchKernelGGL(point_kernel, dim3(c->ga_blocks), dim3(256), (size_t)(a.pb * (c->CZp + c->Q) + c->Q) * sizeof(double), c->stream, a);
     GP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, c->gapart, c->ga_blocks, c->Q, c->Q, ga);
-  } else if (widefix || p2i8) {
+  } else if (widefix) {
     hipLaunchKernelGGL(colsum2_kernel, dim3(c->Q), dim3(256), 0, c->stream, c->T2, c->M, c->Q, (const double*)nullptr, 0, 0, c->Q, ga);
   } else {
     const int hb = blocks * 8, hstride = 4 * nrb;    // one partial row of grad_alpha's mu^2 term per wave

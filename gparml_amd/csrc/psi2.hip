@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
 #ifdef GPARML_PAIRS_FEXP      // timing build: the table-free exp (17 instead of 12 FP64 instructions, no ds_bpermute): is the loop bound by the LDS crossbar?
     acc0 += fexp(e[0]) + fexp(e[2]);
     acc1 += fexp(e[1]) + fexp(e[3]);
+#elif defined(GPARML_PAIRS_VTAB)   // the table lookup as a global load (vmcnt) instead of two ds_bpermute (lgkmcnt, shared with the scalar row loads)
+    acc0 += fexp_v(e[0], kExp2Tab64) + fexp_v(e[2], kExp2Tab64);
+    acc1 += fexp_v(e[1], kExp2Tab64) + fexp_v(e[3], kExp2Tab64);
 #else
     acc0 += fexp_t(e[0], xt) + fexp_t(e[2], xt);
     acc1 += fexp_t(e[1], xt) + fexp_t(e[3], xt);
@@ -312,9 +315,20 @@ __global__ void __launch_bounds__(256) psi2_reduce64_kernel(const double* __rest
   }
 }
 
-// zero the M x M block (and pads) of Psi2 before the pair reduce writes it
-__global__ void fill_kernel(double* x, long n, double v) {
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) x[i] = v;
+// Psi2's padding (rows / columns M .. Mp - 1): the global step's products run over Mp, and the reduce kernels above write the M x M block only.  Until r06 these
+// zeros were whatever the allocation left (the poison run found it: K_mm^-1 Psi2 all NaN); one small launch per evaluation, nothing when M = Mp.
+__global__ void __launch_bounds__(256) psi2_pad_zero_kernel(double* __restrict__ Psi2, int M, int Mp) {
+  const long total = (long)Mp * Mp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int r = (int)(i / Mp), cidx = (int)(i - (long)r * Mp);
+    if (r >= M || cidx >= M) Psi2[i] = 0.0;
+  }
+}
+int psi2_zero_pads(gp_ctx* c) {
+  if (c->M == c->Mp) return GP_OK;
+  hipLaunchKernelGGL(psi2_pad_zero_kernel, dim3((unsigned)std::min<long>(((long)c->Mp * c->Mp + 255) / 256, 1024)), dim3(256), 0, c->stream, c->stats, c->M, c->Mp);
+  GP_HIP(c, hipGetLastError());
+  return GP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- phase 2
@@ -344,7 +358,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 
 template <int QT, bool KEEP>
-__global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_cols_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
+__global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
                                                         const double* __restrict__ LEA, const double* __restrict__ V2P,
                                                         const double* __restrict__ WP, const double* __restrict__ MUP,
                                                         const double* __restrict__ alphaP) {
@@ -372,7 +386,7 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_c
       const double* lrow = LEA + n * a.Mp;               // wave-uniform row of this point
       const double lea = lrow[mc];
       const double* bcol = Bbar + mc;
-      constexpr int U = QT <= 10 ? 4 : (QT <= 16 ? 2 : 1);   // rows per trip: U z-rows (2 QT SGPRs each) must fit the scalar file
+      constexpr int U = QT <= 10 ? 4 : 2;   // rows per trip: U z-rows (2 QT SGPRs each) must fit the scalar file
       for (int m = 0; m < Mr; m += U) {
         double bb[U];
 #pragma unroll
@@ -435,21 +449,24 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : (QT <= 16 ? 2 : 1)) psi2_c
 // the slabs (a round = disjoint slab pairs, one per wave, rounds separated by a barrier), so no two waves ever touch the same rows
 // of rt at the same time: plain read-add-write in a fixed order, no atomics, results bit-identical from run to run.  When all
 // rounds are done every thread finishes its rows (grad_Z of the row, the per-point sums) exactly as the column kernel does.
+__host__ __device__ constexpr int sym_rs(int QT) { return QT <= 10 ? (QT + 1 + 3) / 4 * 4 : QT + 1; }
+
 template <int QT>
-__global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
+__global__ void __launch_bounds__(512, QT <= 12 ? 3 : 2) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
                                                        const double* __restrict__ Bbar, const double* __restrict__ LEA,
                                                        const double* __restrict__ V2P, const double* __restrict__ WP,
                                                        const double* __restrict__ MUP, const double* __restrict__ alphaP,
                                                        const int* __restrict__ sched, int nrounds) {
-  constexpr int RT = (QT + 1 + 3) / 4 * 4, NQ = RT / 4, PW = 3 * QT + 1;
+  // RT: feature columns of the row-side MFMAs ([Z | 1] padded to four); RS: row stride of rt -- RT up to QT = 10 (r03 layout), QT + 1 beyond: the
+  // array is what limits the workgroups per CU (M = 512: 52 KB at QT = 12 -> three workgroups, 64 KB with the padded stride -> two)
+  constexpr int RT = (QT + 1 + 3) / 4 * 4, NQ = RT / 4, PW = 3 * QT + 1, RS = sym_rs(QT);
   extern __shared__ double smem[];
-  double* rt = smem;                       // [Mp][RT]   t_m[q] (q < QT), r_m (index QT) of the current point
-  double* red = rt + (long)a.Mp * RT;      // [waves][PW]
+  double* rt = smem;                       // [Mp][RS]   t_m[q] (q < QT), r_m (index QT) of the current point
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;
   const long n0 = (long)blockIdx.x * a.ppb, n1 = min(a.N, n0 + a.ppb);
-  for (int i = tid; i < a.Mp * RT; i += blockDim.x) rt[i] = 0.0;
+  for (int i = tid; i < a.Mp * RS; i += blockDim.x) rt[i] = 0.0;
   __syncthreads();
   for (long n = n0; n < n1; ++n) {
     const double* v2 = V2P + n * QT;                   // wave-uniform
@@ -469,12 +486,16 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
         for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * ZP[(long)mc * QT + q]; t[q] = 0.0; }
         const double lea = lrow[mc];
         const double* bcol = Bbar + mc;
+        // the row side's B operand [Z | 1] of slab J: 4 NQ values per lane.  Up to QT = 10 they stay in registers for the tile; beyond, the kernel is at its
+        // register limit (three waves per SIMD: 170) and they are re-read for every group of four rows (16 L1 hits per 4 x 64 pairs)
+        constexpr bool ZBLIVE = QT <= 10;
         double ZB[4][NQ];
-        if (offd) {
+        const double* zbp = Z1S + (long)(64 * J + 16 * lk + 4 * lb) * RT + lq;
+        if (offd && ZBLIVE) {
 #pragma unroll
           for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = Z1S[(long)(64 * J + 16 * lk + 4 * lb + v) * RT + 4 * qq + lq];
+            for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = zbp[v * RT + 4 * qq];
         }
         double bbn[4];                                      // Bbar of the next group of rows, one group ahead
 #pragma unroll
@@ -494,23 +515,33 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
             double e = lrow[m0 + u] + lea;                  // these operands made hipcc spill SGPRs through v_writelane: +20 %)
 #pragma unroll
             for (int q = 0; q < QT; ++q) e = fma(zm[q], zz[q], e);
+#ifdef GPARML_SYM_VTAB
+            T[u] = bb[u] * fexp_v(e, kExp2Tab64);
+#else
             T[u] = bb[u] * fexp(e);
+#endif
             r += T[u];
 #pragma unroll
             for (int q = 0; q < QT; ++q) t[q] = fma(T[u], zm[q], t[q]);
           }
           if (offd) {
             double acc[NQ];
+            if (!ZBLIVE) {
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = zbp[v * RT + 4 * qq];
+            }
             wave_rows_times_features<NQ>(T, ZB, acc);
             if (lb == 0) {
-              double* dst = rt + (m0 + lk) * RT + lq;
+              double* dst = rt + (m0 + lk) * RS + lq;
 #pragma unroll
-              for (int qq = 0; qq < NQ; ++qq) dst[4 * qq] += acc[qq];
+              for (int qq = 0; qq < NQ; ++qq) if (RS == RT || 4 * qq + lq <= QT) dst[4 * qq] += acc[qq];      // features beyond the ones column are padding
             }
           }
         }
         // column side of this tile into rt (rows of slab J)
-        double* dst = rt + mc * RT;
+        double* dst = rt + mc * RS;
 #pragma unroll
         for (int q = 0; q < QT; ++q) dst[q] += t[q];
         dst[QT] += r;
@@ -524,7 +555,7 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
 #pragma unroll
     for (int q = 0; q < QT; ++q) { s1[q] = 0.0; s2[q] = 0.0; s3[q] = 0.0; }
     for (int m = tid; m < a.Mp; m += blockDim.x) {
-      double* src = rt + m * RT;
+      double* src = rt + m * RS;
       const double r = src[QT];
       src[QT] = 0.0;
       s0 += r;
@@ -538,218 +569,17 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
         s1[q] = fma(zq, r, s1[q]); s2[q] = fma(zq * zq, r, s2[q]); s3[q] = fma(zq, tq, s3[q]);
       }
     }
+    // the waves' sums go to pp as they are, one group per wave (a.ngrp = waves): psi2_points_finish_kernel adds the groups in wave order -- the order the
+    // LDS hand-over of r03-r05 used, so the bits are the same -- and the [waves][PW] LDS array with its second barrier is gone (r06)
+    double* ppw = a.pp + (long)wave * PW * a.Np + n;
     s0 = wave_sum(s0);
-    if (lane == 0) red[wave * PW] = s0;
+    if (lane == 0) ppw[0] = s0;
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
       const double x1 = wave_sum(s1[q]), x2 = wave_sum(s2[q]), x3 = wave_sum(s3[q]);
-      if (lane == 0) { red[wave * PW + 1 + q] = x1; red[wave * PW + 1 + QT + q] = x2; red[wave * PW + 1 + 2 * QT + q] = x3; }
+      if (lane == 0) { ppw[(long)(1 + q) * a.Np] = x1; ppw[(long)(1 + QT + q) * a.Np] = x2; ppw[(long)(1 + 2 * QT + q) * a.Np] = x3; }
     }
-    __syncthreads();
-    for (int i = tid; i < PW; i += blockDim.x) {
-      double sum = red[i];
-      for (int w = 1; w < nw; ++w) sum += red[w * PW + i];
-      a.pp[(long)i * a.Np + n] = sum;
-    }
-    // red is rewritten only behind the next point's round barriers; rt rows were cleared before the barrier above
-  }
-}
-
-// ---- wide latent spaces (Q >= 25): the same column ownership on the matrix core.  A row of z_m no longer fits the scalar
-// register file (2 QT SGPRs), so the two Q-contractions become 4x4x4 FP64 MFMAs fed from LDS:
-//   GEMM1  E[m, m'] = sum_q Z1[m, q] * ZZ_n[m', q]            (ZZ_n = -2 V_n o Z, zero beyond Q)
-//   T = Bbar o exp(E + LEA[n, m] + LEA[n, m'])                 (VALU, on the accumulator registers)
-//   GEMM2  t[m', q] = sum_m T[m, m'] * Z1[m, q]                (Z1 = Z with a column of ones at index Q: that column is r)
-// A workgroup = 4 waves x 16 columns, walks the rows in strips of 16 (staged once in LDS for the four waves).  One
-// instruction is a 16 x 4 output tile (mma_f64.h); the T registers are used AS the A operand of GEMM2: the operand map
-// A_b[i = l&3][k = l>>4] reads a result register D_b[i = l>>4][j = l&3] transposed, which is exactly T^T restricted to the
-// block's four rows, so no LDS round trip is needed.  Each of the four blocks then holds the partial sum over its own
-// row quad; they are added once per point.  Same pipe as the VALU: the gain is operand delivery.
-template <int QT>
-__global__ void __launch_bounds__(256, 2) psi2_cols_mfma_kernel(PB2Args a, const double* __restrict__ Z1P, const double* __restrict__ Bbar,
-                                                                const double* __restrict__ LEA, const double* __restrict__ V2P,
-                                                                const double* __restrict__ WP, const double* __restrict__ MUP,
-                                                                const double* __restrict__ alphaP) {
-  constexpr int NQ = QT / 4;                       // q quads
-  constexpr int LDZ = QT + 2;                      // LDS row stride: (QT+2)/2 is odd for QT = 32, 52, 64, so the 16 rows of an A-operand
-                                                   // read land on 16 distinct even bank pairs (conflict-free)
-  constexpr int PW = 3 * QT + 1;
-  constexpr int RB = 2, SR = 16 * RB;              // a strip = RB row blocks of 16 = 32 rows (two workgroups per CU fit the LDS)
-  extern __shared__ double smem[];
-  double* zs = smem;                               // [2][SR][LDZ]  row strips of Z1
-  double* zzs = zs + 2 * SR * LDZ;                 // [4][16][LDZ]  per wave: ZZ_n of its 16 columns
-  double* lrow = zzs + 4 * 16 * LDZ;               // [Mp]          LEA[n, :]
-  double* red = lrow + a.Mp;                       // [4][PW]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
-  const int c0 = blockIdx.y * 64 + wave * 16;      // first column of this wave (< Mp)
-  double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;
-  double* zzw = zzs + wave * 16 * LDZ;
-  const long n0 = (long)blockIdx.x * a.ppb, n1 = min(a.N, n0 + a.ppb);
-  const int nstrip = (a.M + SR - 1) / SR;          // 64 * nstrip <= Mp
-  // strip staging: SR rows x QT doubles are contiguous in Z1P; thread t moves elements t, t+256, ...
-  constexpr int SE = SR * QT, SPT = (SE + 255) / 256;
-  const int aofs = (4 * lb + li) * LDZ + lk;       // A_b[i][k]  = Z1[r0 + 16 rb + 4b + i][4 k4 + k]   (+ 16 rb LDZ + 4 k4)
-  const int bofs = li * LDZ + lk;                  // B[k][j]    = ZZ[c0 + 4 cq + j][4 k4 + k]          (+ 4 cq LDZ + 4 k4)
-  const int b2ofs = (4 * lb + lk) * LDZ + li;      // B2_b[k][j] = Z1[r0 + 16 rb + 4b + k][4 qq + j]   (+ 16 rb LDZ + 4 qq)
-  for (long n = n0; n < n1; ++n) {
-    // ---- per-point operands
-    for (int m = tid; m < a.Mp; m += 256) lrow[m] = LEA[n * a.Mp + m];
-    for (int e = lane; e < 16 * QT; e += 64) {
-      const int j = e / QT, q = e - j * QT;
-      zzw[j * LDZ + q] = V2P[n * QT + q] * Z1P[(long)(c0 + j) * QT + q];
-    }
-    double lcol[4];
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) lcol[cq] = LEA[n * a.Mp + c0 + 4 * cq + li];
-    double tacc[4][NQ];
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq)
-#pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) tacc[cq][qq] = 0.0;
-    double stage[SPT];
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; stage[i] = e < SE ? Z1P[e] : 0.0; }
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; if (e < SE) zs[(e / QT) * LDZ + (e % QT)] = stage[i]; }
-    __syncthreads();
-    for (int s = 0; s < nstrip; ++s) {
-      const double* zb = zs + (s & 1) * SR * LDZ;
-      const int r0 = SR * s;
-      if (s + 1 < nstrip) {
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; stage[i] = e < SE ? Z1P[(long)(r0 + SR) * QT + e] : 0.0; }
-      }
-      // Bbar for the 16 result registers: row r0 + 16 rb + 4 lb + lk, column c0 + 4 cq + li
-      double bb[RB][4];
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const double* brow = Bbar + (long)(r0 + 16 * rb + 4 * lb + lk) * a.Mp + c0 + li;
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) bb[rb][cq] = brow[4 * cq];
-      }
-      // GEMM1 (operands of step k4+1 are read while the 8 MFMAs of step k4 execute).  Operand reads are explicit ds_read_b64 with
-      // counted waits and the MFMAs asm (mma_f64.h): left to hipcc, the two A reads of a step merge into ds_read2_b64, which is
-      // serviced in 16-lane groups over 32 banks and turns the stride-(QT+2) image into a 2-way conflict (PMC: 3.4e9 conflict
-      // cycles against 5.1e9 active LDS cycles per launch at Q = 50, M = 1024)
-      double E[RB][4];
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) E[rb][cq] = 0.0;
-      {
-        const unsigned aA = lds_byte_addr(zb) + 8u * (unsigned)aofs, aB = lds_byte_addr(zzw) + 8u * (unsigned)bofs;
-        double av[2][RB], bv[2][4];
-        auto rd = [&](auto kc, double (&a_)[RB], double (&b_)[4]) {
-          constexpr int k4 = decltype(kc)::value;
-          static_for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; a_[rb] = ds_read64<(16 * rb * LDZ + 4 * k4) * 8>(aA); });
-          static_for<0, 4>([&](auto cc) { constexpr int cq = decltype(cc)::value; b_[cq] = ds_read64<(4 * cq * LDZ + 4 * k4) * 8>(aB); });
-        };
-        rd(IC<0>{}, av[0], bv[0]);
-        static_for<0, NQ>([&](auto kc) {
-          constexpr int k4 = decltype(kc)::value, cur = k4 & 1;
-          if constexpr (k4 + 1 < NQ) { rd(IC<k4 + 1>{}, av[cur ^ 1], bv[cur ^ 1]); lgkm_wait<RB + 4>(); }
-          else lgkm_wait<0>();
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int cq = 0; cq < 4; ++cq) mfma444_acc(E[rb][cq], av[cur][rb], bv[cur][cq]);
-        });
-        mfma_drain(E[RB - 1][3]);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc_fence<4>(E[rb]);
-      }
-      // T = Bbar o exp(E + LEA[n, row] + LEA[n, col]) on the result registers
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const double lr = lrow[r0 + 16 * rb + 4 * lb + lk];
-#pragma unroll
-        for (int cq = 0; cq < 4; ++cq) E[rb][cq] = bb[rb][cq] * fexp(E[rb][cq] + lr + lcol[cq]);
-      }
-      // GEMM2: tacc[cq][qq] += sum_rb T[rb][cq]^T . B2[rb][qq]   (same read / wait scheme; the s_nop covers the VALU -> MFMA
-      // operand hazard the compiler cannot see through the asm)
-      {
-        const unsigned aB2 = lds_byte_addr(zb) + 8u * (unsigned)b2ofs;
-        double b2[2][RB];
-        auto rd2 = [&](auto qc, double (&b_)[RB]) {
-          constexpr int qq = decltype(qc)::value;
-          static_for<0, RB>([&](auto rc) { constexpr int rb = decltype(rc)::value; b_[rb] = ds_read64<(16 * rb * LDZ + 4 * qq) * 8>(aB2); });
-        };
-        rd2(IC<0>{}, b2[0]);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc_fence<4>(E[rb]);
-        asm volatile("s_nop 4");
-        static_for<0, NQ>([&](auto qc) {
-          constexpr int qq = decltype(qc)::value, cur = qq & 1;
-          if constexpr (qq + 1 < NQ) { rd2(IC<qq + 1>{}, b2[cur ^ 1]); lgkm_wait<RB>(); }
-          else lgkm_wait<0>();
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int cq = 0; cq < 4; ++cq) mfma444_acc(tacc[cq][qq], E[rb][cq], b2[cur][rb]);
-        });
-      }
-      if (s + 1 < nstrip) {
-        double* zn = zs + ((s + 1) & 1) * SR * LDZ;
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) { const int e = tid + 256 * i; if (e < SE) zn[(e / QT) * LDZ + (e % QT)] = stage[i]; }
-      }
-      __syncthreads();
-    }
-    // ---- per point: add the four row-quad partials (lanes that differ in bits 2,3), then lane (lk, li) holds
-    //      t[column c0 + 4 cq + lk][q = 4 qq + li] in every block
-    const int Qq = a.Q >> 2, Qj = a.Q & 3;          // the ones column (index Q) sits in quad Qq, position Qj
-    mfma_drain(tacc[3][NQ - 1]);
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) acc_fence<NQ>(tacc[cq]);
-    double rcol[4];
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) {
-#pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) {
-        double v = tacc[cq][qq];
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8);
-        tacc[cq][qq] = v;
-      }
-      double rv = 0.0;
-#pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) if (qq == Qq) rv = tacc[cq][qq];
-      rcol[cq] = __shfl(rv, (lane & ~3) | Qj);     // r of column c0 + 4 cq + lk, for every li
-    }
-    double s0 = 0.0;
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) s0 += rcol[cq];
-    s0 += __shfl_xor(s0, 16);
-    s0 += __shfl_xor(s0, 32);                      // sum over the wave's 16 columns (identical in every lane)
-#pragma unroll
-    for (int qq = 0; qq < NQ; ++qq) {
-      const int q = 4 * qq + li;
-      const double al = alphaP[q], wq = WP[n * QT + q], muq = MUP[n * QT + q];
-      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int cq = 0; cq < 4; ++cq) {
-        const int col = c0 + 4 * cq + lk;
-        const double zq = (q < a.Q) ? Z1P[(long)col * QT + q] : 0.0;      // the ones column is not a latent dimension
-        const double r = rcol[cq], t = (q < a.Q) ? tacc[cq][qq] : 0.0;
-        // grad_Z of (col, q) accumulates in this workgroup's partial (26 KB per workgroup: it lives in L2); the four
-        // blocks hold identical totals, block 0 writes
-        if (lb == 0 && col < a.M && q < a.Q) {
-          double* dst = G + (long)col * a.Q + q;
-          *dst = ((n == n0) ? 0.0 : *dst) - al * (zq * r - t) + wq * (2.0 * muq * r - zq * r - t);
-        }
-        s1 = fma(zq, r, s1); s2 = fma(zq * zq, r, s2); s3 = fma(zq, t, s3);
-      }
-      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-      s3 += __shfl_xor(s3, 16); s3 += __shfl_xor(s3, 32);
-      if (lane < 4) { red[wave * PW + 1 + q] = s1; red[wave * PW + 1 + QT + q] = s2; red[wave * PW + 1 + 2 * QT + q] = s3; }
-    }
-    if (lane == 0) red[wave * PW] = s0;
-    __syncthreads();
-    for (int i = tid; i < PW; i += 256)
-      a.pp[((long)blockIdx.y * PW + i) * a.Np + n] = red[i] + red[PW + i] + red[2 * PW + i] + red[3 * PW + i];
-    __syncthreads();
+    __syncthreads();       // every row of rt has been read and cleared before the next point's tiles add to it
   }
 }
 
@@ -805,10 +635,8 @@ __global__ void __launch_bounds__(256) pb2_reduce_kernel(const double* __restric
 }
 
 template <typename T>
-static int balloc(gp_ctx* c, T** p, size_t count) {
-  GP_HIP(c, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
-  GP_HIP(c, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
-  return GP_OK;
+static int balloc(gp_ctx* c, T** p, size_t count, int mode = DA_INIT) {
+  return dalloc_bytes(c, (void**)p, count * sizeof(T), mode);
 }
 
 int ensure_regime_b_buffers(gp_ctx* c) {
@@ -820,10 +648,14 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   // pair of every point pays 2 QB + 20 issue slots whatever Q is (N = 1e5, M = 512, same box: Q = 5, 6: 44.6 -> 39.0 ms per evaluation; Q = 7, 8: -4 %, the
   // tile-pair kernel's row tables are 12 wide at 8 as at 10); 12 and 14 next to 16 (the column kernel): Q = 12: 63.9 -> 57.1 ms, Q = 14: 65.8 -> 61.8 ms
   c->QB = Q <= 4 ? 4 : Q <= 6 ? 6 : Q <= 8 ? 8 : Q <= 10 ? 10 : Q <= 12 ? 12 : Q <= 14 ? 14 : Q <= 16 ? 16 : Q <= 24 ? 24 : Q <= 31 ? 32 : Q <= 51 ? 52 : 64;
+  if (b_generic(c)) c->QB = (int)Q;       // psi2_generic.hip: the tables are exactly Q wide
   c->b_mfma = Q >= 25 && Q < c->QB;
   A(&c->LE, (size_t)Np * Mp); A(&c->LET, (size_t)Np * Mp); A(&c->Vn, (size_t)Np * Q); A(&c->Wn, (size_t)Np * Q);
-  A(&c->V2P, (size_t)Np * c->QB); A(&c->ZP, (size_t)Mp * c->QB); A(&c->Z1P, (size_t)Mp * c->QB); A(&c->WP, (size_t)Np * c->QB); A(&c->MUP, (size_t)Np * c->QB);
-  A(&c->alphaP, (size_t)c->QB);
+  A(&c->ZP, (size_t)Mp * c->QB); A(&c->Z1P, (size_t)Mp * c->QB);
+  // zero contract: columns Q .. QB - 1 of the per-point tables and of alphaP are never written (b_tables_kernel fills q < Q) and every kernel runs its q loops to QB
+  auto A0 = [&](auto** p, size_t n) { if (rc == GP_OK) rc = balloc(c, p, n, DA_ZERO); };
+  A0(&c->V2P, (size_t)Np * c->QB); A0(&c->WP, (size_t)Np * c->QB); A0(&c->MUP, (size_t)Np * c->QB);
+  A0(&c->alphaP, (size_t)c->QB);
   A(&c->lnc2h, (size_t)Np);
   // phase-2 pair kernel: grid (point chunks, groups of <= 4 64-column slabs); >= 16 points per workgroup, <= 4096 chunks
   c->nslab = (int)((M + 63) / 64);
@@ -846,14 +678,20 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   // ... and its per-point array rt (Mp x RT doubles of LDS per workgroup) must leave room for twelve waves per CU: with fewer
   // the scalar-operand latency is exposed and the column kernel (four waves per SIMD) is faster (M = 1024: one workgroup per CU)
   {
-    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2, RTs = (c->QB + 1 + 3) / 4 * 4;
-    const size_t smem = ((size_t)Mp * RTs + (size_t)nw * (3 * c->QB + 1)) * sizeof(double);
-    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
+    // r06: latent tables up to 16 wide (rt rows QB + 1 doubles apart beyond QB = 10, no second LDS array): at M = 512 three workgroups per CU up to QB = 12, two at
+    // 14 and 16 (eight waves per CU; GPARML_B_SYM_MAXQ = 10 restores the column kernel there for a same-box A/B)
+    static const int maxq = [] { const char* e = getenv("GPARML_B_SYM_MAXQ"); return e ? atoi(e) : 16; }();
+    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2;
+    const size_t smem = (size_t)Mp * sym_rs(c->QB) * sizeof(double);
+    c->b_sym = !c->b_mfma && c->QB <= std::min(maxq, 16) && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 &&
+               (160 * 1024 / smem) * nw >= (size_t)(c->QB <= 12 ? 12 : 8);
+    c->sym_nw = nw;
   }
   // the matrix-core tile-pair phase 2 (psi2_tile.hip) wherever psi2_sym_kernel does not apply; it keeps its own per-launch sums buffer
-  c->b_tile = pt2_applicable(c, c->b_sym);
+  c->b_tile = !b_generic(c) && pt2_applicable(c, c->b_sym);
   if (c->b_tile) c->b_sym = false;
-  A(&c->pp, c->b_tile ? 1 : (size_t)Np * (3 * c->QB + 1) * (c->b_mfma ? c->nslab : (c->nslab + 3) / 4));
+  c->pp_doubles = c->b_tile ? 1 : (size_t)Np * (3 * c->QB + 1) * (c->b_sym ? c->sym_nw : (c->nslab + 3) / 4);     // one group of sums per wave (sym) / per four slabs (cols)
+  A(&c->pp, c->pp_doubles);
   std::vector<int> sch;
   if (c->b_sym) {
     const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2;
@@ -879,7 +717,7 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   if (need > c->part_doubles) {
     (void)hipFree(c->part);
     c->part = nullptr;
-    GP_HIP(c, hipMalloc((void**)&c->part, need * 8));
+    GP_TRY_RC(dalloc_bytes(c, (void**)&c->part, need * 8, DA_RAW));
     c->part_doubles = need;
   }
   c->b_alloc = true;
@@ -889,7 +727,7 @@ int ensure_regime_b_buffers(gp_ctx* c) {
 // (z_mq - z_m'q)^2 for the compat path's per-point psi2 tensor only (the pair kernels use the padded Z tables)
 int run_dz2(gp_ctx* c) {
   const long total = (long)c->M * c->M * c->Q;
-  if (!c->DZ2) GP_HIP(c, hipMalloc((void**)&c->DZ2, std::max<long>(total, 1) * sizeof(double)));
+  if (!c->DZ2) GP_TRY_RC(dalloc_bytes(c, (void**)&c->DZ2, (size_t)std::max<long>(total, 1) * sizeof(double), DA_RAW));
   hipLaunchKernelGGL(dz2_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, c->stream, c->Z, c->M, c->Q, c->DZ2);
   GP_HIP(c, hipGetLastError());
   return GP_OK;
@@ -910,6 +748,7 @@ int run_generate_b(gp_ctx* c) {
   GP_HIP(c, hipMemcpyAsync(c->alphaP, c->alpha, (size_t)c->Q * 8, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(zpad_kernel, dim3((unsigned)(((long)c->Mp * (c->QB + 6) + 255) / 256)), dim3(256), 0, c->stream, c->Z, c->M, c->Mp, c->Q, c->QB,
                      c->ZP, c->Z1P, c->b_sym ? c->Z1S : nullptr, (c->QB + 1 + 3) / 4 * 4);
+  if (b_generic(c)) return run_le_generic(c);
   switch (c->QB) {
     case 4: launch_le<4, 2>(c); break;
     case 6: launch_le<6, 2>(c); break;
@@ -940,6 +779,7 @@ static void launch_pairs_mfma(gp_ctx* c, int S) {
 }
 
 int run_phase1_b(gp_ctx* c) {
+  if (b_generic(c)) { GP_TRY_RC(run_phase1_b_generic(c)); return psi2_zero_pads(c); }
   // gp_last_timings' "p1 kernel" slot: in regime B the Psi2 pair kernel (the C tiles' p1_kernel8 launch recorded the events before)
   GP_EV(c, 10);
   // the matrix-core pair kernel from the 24-wide latent tables on (17 <= Q): same-box, N = 1e5, M = 512, ms of this kernel at Q = 17 / 20 / 24:
@@ -958,12 +798,11 @@ int run_phase1_b(gp_ctx* c) {
     GP_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(psi2_reduce64_kernel, dim3(c->n_tiles64), dim3(256), 0, c->stream, c->part, c->tiles64, c->n_tiles64, S, c->M, c->Mp, c->stats);
     GP_HIP(c, hipGetLastError());
-    return GP_OK;
+    return psi2_zero_pads(c);
   }
   // n-slices: many more workgroups than resident slots (256 CUs x 7) so the last round is short, >= 1024 points per slice
   int S = (int)std::max<long>(1, std::min<long>(64, std::max<long>((4096 + c->n_ptiles - 1) / c->n_ptiles, c->N / 1024)));
   S = (int)std::min<long>(S, c->N);
-  if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
   switch (c->QB) {
     case 4: launch_pairs<4>(c, S); break;
     case 6: launch_pairs<6>(c, S); break;
@@ -972,16 +811,13 @@ int run_phase1_b(gp_ctx* c) {
     case 12: launch_pairs<12>(c, S); break;
     case 14: launch_pairs<14>(c, S); break;
     case 16: launch_pairs<16>(c, S); break;
-    case 24: launch_pairs<24>(c, S); break;
-    case 32: launch_pairs<32>(c, S); break;
-    case 52: launch_pairs<52>(c, S); break;
-    default: launch_pairs<64>(c, S); break;
+    default: return fail(c, GP_ERR_UNSUPPORTED, "regime-B pair kernel: no instantiation for the latent table width %d", c->QB);
   }
   GP_EV(c, 11);
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_reduce_kernel, dim3(c->n_ptiles), dim3(256), 0, c->stream, c->part, c->ptiles, c->n_ptiles, S, c->M, c->Mp, c->stats);
   GP_HIP(c, hipGetLastError());
-  return GP_OK;
+  return psi2_zero_pads(c);
 }
 
 template <int QT, bool KEEP>
@@ -994,8 +830,7 @@ static void launch_cols(gp_ctx* c, const PB2Args& a) {
 
 template <int QT>
 static int launch_sym(gp_ctx* c, const PB2Args& a) {
-  constexpr int RT = (QT + 1 + 3) / 4 * 4;
-  const size_t smem = ((size_t)c->Mp * RT + (size_t)c->sym_nw * (3 * QT + 1)) * sizeof(double);
+  const size_t smem = (size_t)c->Mp * sym_rs(QT) * sizeof(double);
   GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_sym_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((psi2_sym_kernel<QT>), dim3(c->pb_blocks), dim3(64 * c->sym_nw), smem, c->stream, a, (const double*)c->ZP, (const double*)c->Z1S,
                      (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
@@ -1003,39 +838,20 @@ static int launch_sym(gp_ctx* c, const PB2Args& a) {
   return GP_OK;
 }
 
-template <int QT>
-static int launch_cols_mfma(gp_ctx* c, const PB2Args& a) {
-  constexpr int LDZ = QT + 2;
-  const size_t smem = ((size_t)(2 * 32 + 4 * 16) * LDZ + c->Mp + 4 * (3 * QT + 1)) * sizeof(double);
-  if (smem > 160 * 1024) return fail(c, GP_ERR_UNSUPPORTED, "regime B, Q >= 25: M = %d needs %zu bytes of LDS", c->M, smem);
-  // a per-device attribute: set on every launch (cheap) rather than once per process -- contexts may live on several GPUs
-  GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_cols_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL((psi2_cols_mfma_kernel<QT>), dim3(c->pb_blocks, c->nslab), dim3(256), smem, c->stream, a, (const double*)c->Z1P,
-                     (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
-                     (const double*)c->alphaP);
-  return GP_OK;
-}
-
 int run_phase2_b(gp_ctx* c) {
-  if (c->Q > 64) return fail(c, GP_ERR_UNSUPPORTED, "regime B supports Q <= 64 (got %d)", c->Q);
   if (c->b_tile) return run_phase2_b_tiles(c);
   PB2Args a;
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
   a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb; a.ngrp = (c->nslab + std::min(4, c->nslab) - 1) / std::min(4, c->nslab);
   GP_EV(c, 12);   // gp_last_timings' "p2 kernel" slot: in regime B the T_n = Bbar o psi2_n kernel
-  if (c->b_mfma) {
-    a.ngrp = c->nslab;
-    int rc = GP_OK;
-    switch (c->QB) {
-      case 32: rc = launch_cols_mfma<32>(c, a); break;
-      case 52: rc = launch_cols_mfma<52>(c, a); break;
-      default: rc = launch_cols_mfma<64>(c, a); break;
-    }
-    if (rc != GP_OK) return rc;
-  } else if (c->b_sym) {
+  if (b_generic(c)) {
     a.ngrp = 1;
-    int rc = c->QB == 4 ? launch_sym<4>(c, a) : c->QB == 6 ? launch_sym<6>(c, a) : c->QB == 8 ? launch_sym<8>(c, a) : launch_sym<10>(c, a);
+    GP_TRY_RC(run_phase2_b_generic(c));
+  } else if (c->b_sym) {
+    a.ngrp = c->sym_nw;
+    int rc = c->QB == 4 ? launch_sym<4>(c, a) : c->QB == 6 ? launch_sym<6>(c, a) : c->QB == 8 ? launch_sym<8>(c, a) : c->QB == 10 ? launch_sym<10>(c, a) :
+             c->QB == 12 ? launch_sym<12>(c, a) : c->QB == 14 ? launch_sym<14>(c, a) : launch_sym<16>(c, a);
     if (rc != GP_OK) return rc;
   } else
   switch (c->QB) {
@@ -1046,16 +862,21 @@ int run_phase2_b(gp_ctx* c) {
     case 12: launch_cols<12, false>(c, a); break;
     case 14: launch_cols<14, false>(c, a); break;
     case 16: launch_cols<16, false>(c, a); break;
-    case 24: launch_cols<24, false>(c, a); break;
-    case 32: launch_cols<32, false>(c, a); break;
-    case 52: launch_cols<52, false>(c, a); break;
-    default: launch_cols<64, false>(c, a); break;
+    default: return fail(c, GP_ERR_UNSUPPORTED, "regime-B column kernel: no instantiation for the latent table width %d (Q = %d runs on psi2_tile_kernel)", c->QB, c->Q);
   }
   GP_EV(c, 13);
   GP_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(psi2_points_finish_kernel, dim3((unsigned)std::min<long>(c->pb_blocks, 256)), dim3(256), 0, c->stream, a);
   GP_HIP(c, hipGetLastError());
   const long MQ = (long)c->M * c->Q;
+  const int fin_blocks_g = (int)std::min<long>(c->pb_blocks, 256);
+  if (b_generic(c)) {
+    // grad_Z's psi2 part is in c->grads already: only the alpha partials of the points' finish are left
+    hipLaunchKernelGGL(pb2_reduce_kernel, dim3((unsigned)std::min<long>((MQ + c->Q + 255) / 256, 1024)), dim3(256), 0, c->stream, c->Gtmp, c->gapart2, 0, fin_blocks_g, MQ,
+                       c->Q, c->grads);
+    GP_HIP(c, hipGetLastError());
+    return GP_OK;
+  }
   const int S2 = std::max(1, std::min(64, c->pb_blocks / 16));
   hipLaunchKernelGGL(pb2_reduce1_kernel, dim3((unsigned)((MQ + 63) / 64), S2), dim3(256), 0, c->stream, c->Gpart, c->pb_blocks, MQ, S2, c->Gtmp);
   const int fin_blocks = (int)std::min<long>(c->pb_blocks, 256);      // psi2_points_finish_kernel's grid (one gapart2 row per workgroup)

@@ -480,12 +480,15 @@ static int launch_tile(gp_ctx* c, const PT2Args& a) {
 // folds and sums do not shrink with Q, so below that the VALU kernels of psi2.hip are faster (same-box, ms of the phase-2 kernel per 1e5
 // points: Q = 4, M = 512: 21.7 (cols) vs 41.8 here; Q = 10, M = 512: 31.7 (psi2_sym) vs 40.5; Q = 16, M = 512: 47.2 vs 56.5;
 // Q = 20, M = 256: 23.1 vs 17.0; Q = 24, M = 512: 93.9 vs 69.7; Q = 50, M = 1024, 2e4 points: 96.4 (psi2_cols_mfma) vs 75.8).
-// GPARML_B_PHASE2=cols keeps the older kernels everywhere, =tiles forces this one.  Decided once per context (c->b_tile).
+// GPARML_B_PHASE2=tiles forces this kernel below Q = 17 as well (tests: every compiled width); =cols keeps the VALU kernels where they exist (Q <= 16).
+// Decided once per context (c->b_tile).  (r06: the column kernels' instantiations for Q >= 17 and psi2_cols_mfma_kernel -- reachable only through =cols,
+// 28-228 B of scratch per lane -- are gone; Q >= 64 runs on psi2_generic.hip.)
 bool pt2_applicable(const gp_ctx* c, bool sym_available) {
   static const int mode = [] { const char* e = getenv("GPARML_B_PHASE2"); return !e ? 0 : (std::string(e) == "cols" ? 1 : (std::string(e) == "tiles" ? 2 : 0)); }();
   (void)sym_available;
-  if (mode == 1 || pt2_width(c->Q) == 0) return false;
-  return mode == 2 || c->Q >= 17;
+  if (pt2_width(c->Q) == 0) return false;
+  if (c->Q >= 17) return true;
+  return mode == 2;
 }
 
 int run_phase2_b_tiles(gp_ctx* c) {
@@ -508,8 +511,8 @@ int run_phase2_b_tiles(gp_ctx* c) {
     // both or neither: a failed second allocation must not leave the first behind (the next call would skip this block and launch with a null Gt).
     // Neither buffer needs zeroing: the first launch of an evaluation (accumulate = 0) writes every pp[t][i][k < count] and all T * S
     // workgroups store their Gt slot unconditionally.
-    GP_HIP(c, hipMalloc((void**)&c->ppt, (size_t)T * PW * ch * sizeof(double)));
-    if (hipMalloc((void**)&c->Gt, (size_t)bestS * T * 2 * 64 * Q * sizeof(double)) != hipSuccess) {
+    GP_TRY_RC(dalloc_bytes(c, (void**)&c->ppt, (size_t)T * PW * ch * sizeof(double), DA_RAW));
+    if (dalloc_bytes(c, (void**)&c->Gt, (size_t)bestS * T * 2 * 64 * Q * sizeof(double), DA_RAW) != GP_OK) {
       (void)hipFree(c->ppt); c->ppt = nullptr; c->Gt = nullptr;
       return fail(c, GP_ERR_HIP, "regime-B tile phase 2: allocation of the grad_Z partial buffer failed");
     }

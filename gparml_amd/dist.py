@@ -75,8 +75,9 @@ def init_native_comm(engine, dist, group=None):
     Nothing collective happens on the new communicator before every rank has agreed -- over torch -- that it can take part: each rank
     probes RCCL on its own (gp_comm_available, and rank 0 also draws the id: both local), the flags are MIN-all-reduced, and only then
     is the id broadcast and ncclCommInitRank entered (with a bounded wait, GPARML_COMM_INIT_TIMEOUT seconds, default 180).  A second
-    agreement after the call covers RCCL refusing the communicator on some rank, and a one-double probe all-reduce checks that the
-    communicator really sums over ``world`` ranks."""
+    agreement right after the call covers RCCL refusing the communicator on some rank (no collective has run on it yet, so the ranks
+    that did join are not left waiting inside one); only then does a one-double probe all-reduce check that the communicator really
+    sums over ``world`` ranks, and a third agreement covers its outcome."""
     import os
     if os.environ.get('GPARML_NATIVE_ALLREDUCE', '1') == '0':
         return _say(-1, '')
@@ -115,18 +116,25 @@ def init_native_comm(engine, dist, group=None):
             ok = True
         except Exception as e:      # noqa: BLE001  (communicator refused on this rank)
             ok, why = False, 'rank %d: %s' % (rank, e)
-        if ok:
-            try:
-                info = _bounded(lambda: engine.comm_info(probe=True), limit, 'gp_comm_info(probe)', rank)
-                if info['ranks'] != world or info['probe_sum'] != float(world):
-                    ok, why = False, 'rank %d: communicator reports %d ranks, probe sum %r, expected %d' % (rank, info['ranks'], info['probe_sum'], world)
-            except Exception as e:      # noqa: BLE001
-                ok, why = False, 'rank %d: %s' % (rank, e)
-        # every rank must take the same path through the two reductions: agree on the outcome, fall back to torch everywhere otherwise
-        if not agree(ok):
+
+        def give_up(reason):
             if getattr(engine, 'has_comm', False):
                 engine.comm_destroy()
-            return _say(rank, why or 'a peer rank failed in gp_comm_init')
+            return _say(rank, reason)
+
+        # agreement (over torch) that EVERY rank holds a communicator, before anything collective runs on it: a rank whose gp_comm_init
+        # raised would never enter the probe all-reduce and the others would sit in ncclAllReduce until the watchdog killed them
+        if not agree(ok):
+            return give_up(why or 'a peer rank failed in gp_comm_init')
+        try:
+            info = _bounded(lambda: engine.comm_info(probe=True), limit, 'gp_comm_info(probe)', rank)
+            if info['ranks'] != world or info['probe_sum'] != float(world):
+                ok, why = False, 'rank %d: communicator reports %d ranks, probe sum %r, expected %d' % (rank, info['ranks'], info['probe_sum'], world)
+        except Exception as e:      # noqa: BLE001
+            ok, why = False, 'rank %d: %s' % (rank, e)
+        # ... and on the probe's outcome: every rank takes the same path through the two reductions, torch everywhere otherwise
+        if not agree(ok):
+            return give_up(why or 'a peer rank saw a wrong probe sum')
     _say(rank, '')
     return True
 

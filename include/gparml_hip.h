@@ -225,10 +225,18 @@ int gp_debug_gemm(int device, int ta, int tb, int m, int n, int k, double alpha,
 int gp_debug_force_staging(int on);
 /* process-wide switches of the global step's extended-precision pieces (both on by default): "dd_kipsi2" -- K_mm^-1 Psi2 accumulated in
  * double-double (the product whose float64 rounding is grad_Z's whole error at cond ~1e10), "refine_E" -- one refinement
- * step of E with a double-double residual.  bench.py times the global step with and without to print their cost. */
+ * step of E with a double-double residual.  bench.py times the global step with and without to print their cost.
+ * "poison_alloc" (also GPARML_POISON=1 at load time): every allocation without a documented zero contract is filled with NaN bytes and
+ * gp_set_globals refills the per-evaluation buffers with them -- a kernel that reads what this evaluation did not write fails
+ * deterministically (tests/test_gpu_poison.py). */
 int gp_debug_set_option(const char* name, int value);
 /* in-place lower Cholesky + inverse of an SPD (n,n) matrix; logdet out; returns GP_ERR_NOT_PD on failure */
 int gp_debug_potrf_inverse(int device, int n, const double* A, double* L, double* Ainv, double* logdet);
+/* device-resident timing of the FP64 MFMA GEMM core: `iters` products of the given shape, milliseconds per product (tools/dev_gemm_bench.py) */
+int gp_debug_gemm_bench(int device, int ta, int tb, int m, int n, int k, int iters, double* ms_out);
+/* raw copy of one of the global step's internal buffers ("Linv", "Inv", "E", "PsiE", "T1", "T2", "dFdK", "Bbar", "Abar", "Bm", "gK", "gs") after a
+ * stream synchronisation; n = capacity of out in doubles (tests/devtools/dev_tail_diff.py) */
+int gp_debug_peek(gp_ctx* ctx, const char* name, double* out, long n);
 
 #ifdef __cplusplus
 }

@@ -23,13 +23,15 @@ _GPU_ORDER = [
     # tier 0: golden fixtures of the reference and the oracle, method by method, then the extended-precision truths
     'test_gpu_parity', 'test_gpu_partial_terms', 'test_gpu_pipeline', 'test_gpu_predict', 'test_gpu_phase2_general',
     'test_gpu_hp_truth', 'test_hp_truth_large', 'test_gpu_global_step', 'test_gpu_linalg',
-    'test_gpu_c_consumer', 'test_gpu_perf_guard', 'test_gpu_resident_scg', 'test_gpu_resident_gd', 'test_gpu_dropout', 'test_gpu_tile_phase2', 'test_gpu_p1_i8', 'test_gpu_fuzz_shapes',
+    'test_gpu_c_consumer', 'test_gpu_resident_scg', 'test_gpu_resident_gd', 'test_gpu_dropout', 'test_gpu_tile_phase2', 'test_gpu_p1_i8', 'test_gpu_fuzz_shapes',
 ]
 _GPU_LATE = [
     # tier 1: properties at the configurations' full sizes (seconds of device time, gigabytes of host data)
     'test_gpu_fullsize', 'test_gpu_index_range', 'test_gpu_config4_scg', 'test_gpu_config4_fullsize',
     # tier 2: several torch processes
     'test_gpu_bench_ranks',
+    # last: absolute kernel durations (a contended or throttled box must not stop the parity files under -x)
+    'test_gpu_perf_guard',
 ]
 
 
@@ -42,6 +44,21 @@ def pytest_collection_modifyitems(session, config, items):
             return (2, _GPU_LATE.index(name))
         return (1, 0)
     items.sort(key=key)            # stable: collection order is kept inside a file and among unlisted files
+    # GPARML_TEST_ORDER=reversed | shuffle:<seed>: the FILES in another order (order inside a file kept) -- round 6's hunt for a failure that was seen
+    # once in a full-suite process and never in isolation (tools/suite_orders.sh)
+    mode = os.environ.get('GPARML_TEST_ORDER', '')
+    if mode:
+        files = []
+        for it in items:
+            f = str(it.fspath)
+            if f not in files:
+                files.append(f)
+        if mode == 'reversed':
+            files.reverse()
+        elif mode.startswith('shuffle:'):
+            import random
+            random.Random(int(mode.split(':')[1])).shuffle(files)
+        items.sort(key=lambda it: files.index(str(it.fspath)))
 
 
 def golden_names():

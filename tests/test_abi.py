@@ -1,8 +1,9 @@
-"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly the symbols that
 include/gparml_hip.h declares; the Python binding knows each of them; no compute calls (no GPU here)."""
 import ctypes
 import os
 import re
+import subprocess
 
 from conftest import ROOT
 
@@ -26,6 +27,14 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, 'gparml_amd', 'libgparml_hip.so'))
     for s in _header_symbols():
         assert hasattr(lib, s), 'library does not export %s' % s
+
+
+def test_library_exports_nothing_the_header_does_not_declare():
+    """header symbols == exported gp_* symbols: an entry point that is not in include/gparml_hip.h is either declared there or made static."""
+    so = os.path.join(ROOT, 'gparml_amd', 'libgparml_hip.so')
+    out = subprocess.run(['nm', '-D', '--defined-only', so], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in 'TW' and ln.split()[-1].startswith('gp_')})
+    assert exported == _header_symbols(), (sorted(set(exported) - set(_header_symbols())), sorted(set(_header_symbols()) - set(exported)))
 
 
 def test_binding_covers_every_declared_symbol():

@@ -25,6 +25,8 @@ def test_headline_kernels_are_not_grossly_slower_than_measured():
             best[k] = min(best.get(k, 1e9), v)
     eng.close()
     assert np.isfinite(out['F'])
+    if max(best.get(k, 0.0) for k in LIMITS) <= 0.0:
+        pytest.skip('no per-phase timings (GPARML_TIMING=0/1 in the environment): nothing to guard')
     print('kernel ms at N = 2e5:', {k: round(best[k], 4) for k in LIMITS})
     for k, lim in LIMITS.items():
         assert best[k] <= lim, '%s = %.3f ms at N = 2e5 (limit %.2f): a headline kernel is grossly slower than measured -- run bench.py' % (k, best[k], lim)

@@ -1,0 +1,57 @@
+"""Poison mode (gp_debug_set_option("poison_alloc", 1); csrc/gp_common.h): every device allocation without a documented zero contract is filled with
+NaN bytes, and gp_set_globals refills everything an evaluation must write before it reads (scratch and partial sums, statistics, the global step's
+matrices, gradients, Psi1, the free-embedding tables).  A kernel that relies on zero-initialised memory nobody promised, or that reads a region this
+evaluation did not write, then returns NaN deterministically instead of a wrong digit once in a thousand runs (round 5 saw one unreproduced
+1e-4 deviation of grad_Z in the tile kernel; the whole GPU suite also runs clean under GPARML_POISON=1: profiles/r06_poison_and_stress.txt).
+Reference behaviour protected: partial_terms.py:190-205, 273-284 (the Psi2 parts of grad_Z / grad_alpha)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from gparml_amd import _lib
+from gparml_amd.engine import ShardEngine
+from oracle import factorised as Fz
+lib = _lib.load()
+assert lib.gp_debug_set_option(b'poison_alloc', 1) == 0
+# (N, D, M, Q, regime, alpha, embedding gradients): fast fixed-embedding path, general phase 2, free embeddings on every phase-2 kernel family
+# (column kernel, tile pairs on the VALU, tile pairs on the matrix core with 2 launches, the generic wide-latent kernel), ragged sizes, M = 1
+SHAPES = [(4096, 100, 512, 10, 'A', 0.3, False), (2000, 10, 128, 13, 'A', 0.2, True), (1000, 7, 130, 10, 'B', 0.3, True), (600, 3, 512, 10, 'B', 0.3, True),
+          (640, 3, 33, 13, 'B', 0.2, True), (9000, 3, 200, 20, 'B', 0.1, True), (300, 2, 40, 30, 'B', 0.08, True), (150, 2, 12, 60, 'B', 0.05, True),
+          (257, 2, 1, 1, 'B', 1.0, True), (129, 1, 1, 1, 'A', 1.0, False)]
+for (N, D, M, Q, regime, alpha, emb) in SHAPES:
+    d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=11, zseed=12, alpha_value=alpha)
+    ref = Fz.evaluate(d['Z'], d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'], want_embeddings=emb)
+    eng = ShardEngine(N, D, M, Q)
+    eng.upload_shard(d['Y'], d['X_mu'], d['X_S'])
+    outs = []
+    for rep in range(3):                              # the second and third evaluation start from buffers the first one filled: refilled with NaN in between
+        eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
+        outs.append(eng.evaluate(emb))
+    eng.close()
+    keys = ['grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'] + (['grad_X_mu', 'grad_X_S'] if emb else [])
+    for out in outs:
+        assert np.isfinite(out['F']) and abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F']), ((N, D, M, Q, regime), out['F'], ref['F'])
+        for k in keys:
+            a, b = np.asarray(out[k], dtype=float), np.asarray(ref[k], dtype=float)
+            assert np.all(np.isfinite(a)), ((N, D, M, Q, regime), k, 'not finite under poison')
+            assert np.max(np.abs(a - b)) <= 1e-5 * np.max(np.abs(b)), ((N, D, M, Q, regime), k, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+            assert np.array_equal(a, np.asarray(outs[0][k], dtype=float)), ((N, D, M, Q, regime), k, 'differs between repeats')
+    print('POISON_OK', N, D, M, Q, regime, flush=True)
+'''
+
+
+def test_every_kernel_family_with_poisoned_allocations_and_scratch(tmp_path):
+    script = tmp_path / 'poison_child.py'
+    script.write_text(CHILD % {'root': ROOT})
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=dict(os.environ))
+    assert r.returncode == 0 and r.stdout.count('POISON_OK') == 10, r.stdout[-1500:] + r.stderr[-3000:]

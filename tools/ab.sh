@@ -17,7 +17,7 @@ for r in $(seq 1 $ROUNDS); do
     lib=$PWD/gparml_amd/lib_$v.so.bin; [ "$v" == "intree" ] && lib=$PWD/gparml_amd/libgparml_hip.so
     env $envs GPARML_LIB=$lib python3 bench.py $ARGS --no-cpu-baseline --no-extra | python3 -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); k = d['config']['device_ms']
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); k = d['config'].get('device_ms') or d['config'].get('kernel_ms')
 print('$spec', round(d['ms_per_step'], 3), 'p2', k['p2_kernel_ms'], 'p1', k['p1_kernel_ms'], 'psi1', k['psi1_ms'], 'global', k['global_ms'], 'total', k['total_ms'])"
   done
 done

@@ -33,4 +33,8 @@ for p in "${pids[@]}"; do wait $p || { echo "build failed"; exit 1; }; done
 objs=()
 for f in "$SRC"/*.hip; do objs+=("$OBJ/$(basename "$f" .hip).o"); done
 hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT"
+# the product library is stamped with the digest __graft_entry__.build() checks (sources + headers + its flags); variant builds are not
+if [ "$OUT" == "$ROOT/gparml_amd/libgparml_hip.so" ] && [ -z "${GPARML_EXTRA_FLAGS}" ]; then
+  python3 -c "import sys, glob, os; sys.path.insert(0, '$ROOT'); import __graft_entry__ as g; R = g.ROOT; print(g._source_digest(sorted(glob.glob(os.path.join(R, 'gparml_amd', 'csrc', '*.hip'))), glob.glob(os.path.join(R, 'gparml_amd', 'csrc', '*.h')) + glob.glob(os.path.join(R, 'include', '*.h'))))" > "$OUT.digest"
+fi
 ls -la "$OUT"

@@ -201,6 +201,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   if (c->sym_sched) (void)hipFree(c->sym_sched);
   if (c->bmap) (void)hipFree(c->bmap);
   if (c->staging) (void)hipFree(c->staging);
+  if (c->p2prog) (void)hipFree(c->p2prog);
   gp::p1v2_free(c);
   gp::p1i8_free(c);
   gp::comm_free(c);

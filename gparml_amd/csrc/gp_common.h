@@ -150,6 +150,8 @@ struct gp_ctx {
   double* gXs = nullptr;      // [N][Q]
   double* gapart = nullptr;   // [blocks][Q] per-block alpha partial sums from the per-point kernel
   int ga_blocks = 0;
+  unsigned long long* p2prog = nullptr;   // p2_fast8_kernel: [slices][MT] tile progress of the workgroups of a slice (kept in step for the L2), bases grow per launch
+  unsigned long long p2_epoch = 0;
   double* hgpart = nullptr;   // partial sums of the fast path's mu^2 term of grad_alpha (per wave, or per 256 points from p2_ga_kernel)
   // regime B (variances > 0): pairwise psi2 kernels; allocated on first use
   bool b_alloc = false;

@@ -131,7 +131,6 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 __device__ __forceinline__ void glds16(const double* gsrc, double* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
-
 __device__ __forceinline__ int swap03(int r) { return (r & ~9) | ((r & 1) << 3) | ((r >> 3) & 1); }
 
 // index (in doubles) of element (r, k) inside a K_CONTIG LDS tile

@@ -670,6 +670,9 @@ struct P2Args {
   double* Rpart; double* HZp;
   int Mp, CXp, CZp, MT, S, tps, ntiles, kbeg, kend, klast; long Np;   // klast: k-steps (of 4) of the final chunk that hold real Y columns
   double* gapart;   // eight-wave fast kernel: [blocks * 8][4 NRB] per-wave partials of grad_alpha's mu^2 term
+  // r06, p2_fast8_kernel: the MT workgroups of a row slice keep in step tile by tile (prog[slice][mt] = base + tiles started), so that the slice's
+  // 128 x (Mp + Dp) rows are fetched from HBM once and found in the XCD's L2 by the other MT - 1 (0 / NULL: free-running)
+  unsigned long long* prog; unsigned long long prog_base;
   long long* dbg;   // timing build (GPARML_GEN8_TIMING): [blocks][8 waves][8 sections] s_memtime totals
 };
 
@@ -784,6 +787,7 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
       glds16(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Ktile) +
                                              (unsigned)(8 * ((16 * ar + 4 * i + e.lk) * (int)p.ld + 2 * (e.dpair ^ (2 * i))))), slab + i * 128);
   };
+  bool in_step = p.prog != nullptr;
   for (int nt = t0; nt < t1; ++nt) {
     const long n0 = (long)nt * TILE;
     const double* Ab = p.Kaug + n0 * p.ld + (long)p.kbeg * KC;
@@ -793,6 +797,26 @@ __global__ void __launch_bounds__(512, 4) p2_fast8_kernel(P2Args p) {
     for (int ar = 0; ar < 4; ++ar)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[ar][j] = 0.0;
+    if (p.prog && nt > t0) {
+      // Keep the slice's MT workgroups in step: nothing synchronises them otherwise, they drift apart over the ~60 tiles of a slice, and once the distance
+      // exceeds what the XCD's 4 MB L2 holds for its sixteen slices every workgroup fetches the slice's rows from HBM itself (same-box FETCH_SIZE: 11.6 GB per
+      // launch in round 4, 14.9 GB in round 5 for the same code, 5.3 GB algorithmic).  Wave 0 publishes "tile nt started" and waits until the others have
+      // started it too -- they are resident (the grid is the chip's capacity: two workgroups per CU), on the same XCD (block id mod 8), and at most one tile
+      // behind.  The wait is bounded: if a partner does not show up within ~0.1 ms (a grid that is not fully resident), this workgroup keeps publishing but stops waiting for good.
+      if (wave == 0) {
+        unsigned long long* mine = p.prog + (long)slice * p.MT;
+        const unsigned long long want = p.prog_base + (unsigned long long)(nt - t0);
+        if (lane == 0) __hip_atomic_store(mine + mt, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (entries of earlier launches carry a smaller base and read as "behind"; the early-exit blocks past the last slice never get here; the other
+        // seven waves meet wave 0 at the first chunk's barrier)
+        for (int spins = 0; in_step; ++spins) {
+          const unsigned long long v = (lane < p.MT) ? __hip_atomic_load(mine + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+          if (__builtin_amdgcn_ballot_w64(v < want) == 0) break;
+          if (spins > 2048) in_step = false;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+    }
     int kc = 0;
     const int b0 = (nc + 1) & 1;                                // buffer of chunk 0; chunk c uses (c + nc + 1) & 1, the last one buf0
     chunk_dma(lds + b0 * 4608, Ab + (long)kc * KC, Bb + (long)kc * KC * p.Mp);
@@ -1353,6 +1377,13 @@ int run_phase2(gp_ctx* c) {
   p.klast = ((c->D - 1) % KC) / 4 + 1;
   const int blocks = 8 * ((S + 7) / 8) * p.MT;
   const int nrb = (c->Q + 1 + 3) / 4;                // fast path: feature columns [mu (Q) | 1] in groups of four
+  p.prog = nullptr; p.prog_base = 0;
+  static const bool p2_sync = [] { const char* e = getenv("GPARML_P2_SYNC"); return !(e && e[0] == '0'); }();
+  // the in-step wait needs every workgroup of the launch resident at once: the grid is sized for two workgroups per CU on 256 CUs
+  if (fast && p2_sync && p.MT > 1 && blocks <= 512) {
+    if (!c->p2prog) GP_TRY_RC(dalloc_bytes(c, (void**)&c->p2prog, (size_t)(c->p2_slices + 8) * p.MT * sizeof(unsigned long long), DA_ZERO));   // zero contract: bases only grow
+    p.prog = c->p2prog; p.prog_base = (unsigned long long)(++c->p2_epoch) << 32;
+  }
   GP_EV(c, 12);
   p.dbg = nullptr;
 #ifdef GPARML_GEN8_TIMING

@@ -449,17 +449,18 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Arg
 // the slabs (a round = disjoint slab pairs, one per wave, rounds separated by a barrier), so no two waves ever touch the same rows
 // of rt at the same time: plain read-add-write in a fixed order, no atomics, results bit-identical from run to run.  When all
 // rounds are done every thread finishes its rows (grad_Z of the row, the per-point sums) exactly as the column kernel does.
-__host__ __device__ constexpr int sym_rs(int QT) { return QT <= 10 ? (QT + 1 + 3) / 4 * 4 : QT + 1; }
-
+// (r06: the same kernel at the latent widths 12, 14 and 16 -- rt rows QT + 1 doubles apart so that three workgroups still fit at QT = 12, the row side's B
+// operand either re-read per group of rows (168 VGPRs, three waves per SIMD) or live at two waves per SIMD -- was built, parity-green and NOT faster than the
+// column kernel: same box, N = 1e5, M = 512, ms of the phase-2 kernel at Q = 12 / 14 / 16: 40.9 / 52.7 / 64.1 (re-read) and 42.5 / 50.7 / 56.9 (live) against
+// 41.0 / 45.1 / 47.7 for psi2_cols_kernel, which runs both sides of every pair but at three waves per SIMD and without the 4 NQ operand registers;
+// profiles/r06_gplvm_experiments.txt.  Removed again.)
 template <int QT>
-__global__ void __launch_bounds__(512, QT <= 12 ? 3 : 2) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
+__global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
                                                        const double* __restrict__ Bbar, const double* __restrict__ LEA,
                                                        const double* __restrict__ V2P, const double* __restrict__ WP,
                                                        const double* __restrict__ MUP, const double* __restrict__ alphaP,
                                                        const int* __restrict__ sched, int nrounds) {
-  // RT: feature columns of the row-side MFMAs ([Z | 1] padded to four); RS: row stride of rt -- RT up to QT = 10 (r03 layout), QT + 1 beyond: the
-  // array is what limits the workgroups per CU (M = 512: 52 KB at QT = 12 -> three workgroups, 64 KB with the padded stride -> two)
-  constexpr int RT = (QT + 1 + 3) / 4 * 4, NQ = RT / 4, PW = 3 * QT + 1, RS = sym_rs(QT);
+  constexpr int RT = (QT + 1 + 3) / 4 * 4, NQ = RT / 4, PW = 3 * QT + 1, RS = RT;      // RT: feature columns of the row-side MFMAs = row stride of rt
   extern __shared__ double smem[];
   double* rt = smem;                       // [Mp][RS]   t_m[q] (q < QT), r_m (index QT) of the current point
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -486,12 +487,10 @@ __global__ void __launch_bounds__(512, QT <= 12 ? 3 : 2) psi2_sym_kernel(PB2Args
         for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * ZP[(long)mc * QT + q]; t[q] = 0.0; }
         const double lea = lrow[mc];
         const double* bcol = Bbar + mc;
-        // the row side's B operand [Z | 1] of slab J: 4 NQ values per lane.  Up to QT = 10 they stay in registers for the tile; beyond, the kernel is at its
-        // register limit (three waves per SIMD: 170) and they are re-read for every group of four rows (16 L1 hits per 4 x 64 pairs)
-        constexpr bool ZBLIVE = QT <= 10;
+        // the row side's B operand [Z | 1] of slab J: 4 NQ values per lane, in registers for the whole tile
         double ZB[4][NQ];
         const double* zbp = Z1S + (long)(64 * J + 16 * lk + 4 * lb) * RT + lq;
-        if (offd && ZBLIVE) {
+        if (offd) {
 #pragma unroll
           for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -526,17 +525,11 @@ __global__ void __launch_bounds__(512, QT <= 12 ? 3 : 2) psi2_sym_kernel(PB2Args
           }
           if (offd) {
             double acc[NQ];
-            if (!ZBLIVE) {
-#pragma unroll
-              for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = zbp[v * RT + 4 * qq];
-            }
             wave_rows_times_features<NQ>(T, ZB, acc);
             if (lb == 0) {
               double* dst = rt + (m0 + lk) * RS + lq;
 #pragma unroll
-              for (int qq = 0; qq < NQ; ++qq) if (RS == RT || 4 * qq + lq <= QT) dst[4 * qq] += acc[qq];      // features beyond the ones column are padding
+              for (int qq = 0; qq < NQ; ++qq) dst[4 * qq] += acc[qq];
             }
           }
         }
@@ -678,13 +671,9 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   // ... and its per-point array rt (Mp x RT doubles of LDS per workgroup) must leave room for twelve waves per CU: with fewer
   // the scalar-operand latency is exposed and the column kernel (four waves per SIMD) is faster (M = 1024: one workgroup per CU)
   {
-    // r06: latent tables up to 16 wide (rt rows QB + 1 doubles apart beyond QB = 10, no second LDS array): at M = 512 three workgroups per CU up to QB = 12, two at
-    // 14 and 16 (eight waves per CU; GPARML_B_SYM_MAXQ = 10 restores the column kernel there for a same-box A/B)
-    static const int maxq = [] { const char* e = getenv("GPARML_B_SYM_MAXQ"); return e ? atoi(e) : 16; }();
-    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2;
-    const size_t smem = (size_t)Mp * sym_rs(c->QB) * sizeof(double);
-    c->b_sym = !c->b_mfma && c->QB <= std::min(maxq, 16) && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 &&
-               (160 * 1024 / smem) * nw >= (size_t)(c->QB <= 12 ? 12 : 8);
+    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2, RTs = (c->QB + 1 + 3) / 4 * 4;
+    const size_t smem = (size_t)Mp * RTs * sizeof(double);
+    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
     c->sym_nw = nw;
   }
   // the matrix-core tile-pair phase 2 (psi2_tile.hip) wherever psi2_sym_kernel does not apply; it keeps its own per-launch sums buffer
@@ -830,7 +819,7 @@ static void launch_cols(gp_ctx* c, const PB2Args& a) {
 
 template <int QT>
 static int launch_sym(gp_ctx* c, const PB2Args& a) {
-  const size_t smem = (size_t)c->Mp * sym_rs(QT) * sizeof(double);
+  const size_t smem = (size_t)c->Mp * ((QT + 1 + 3) / 4 * 4) * sizeof(double);
   GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_sym_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((psi2_sym_kernel<QT>), dim3(c->pb_blocks), dim3(64 * c->sym_nw), smem, c->stream, a, (const double*)c->ZP, (const double*)c->Z1S,
                      (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
@@ -850,8 +839,7 @@ int run_phase2_b(gp_ctx* c) {
     GP_TRY_RC(run_phase2_b_generic(c));
   } else if (c->b_sym) {
     a.ngrp = c->sym_nw;
-    int rc = c->QB == 4 ? launch_sym<4>(c, a) : c->QB == 6 ? launch_sym<6>(c, a) : c->QB == 8 ? launch_sym<8>(c, a) : c->QB == 10 ? launch_sym<10>(c, a) :
-             c->QB == 12 ? launch_sym<12>(c, a) : c->QB == 14 ? launch_sym<14>(c, a) : launch_sym<16>(c, a);
+    int rc = c->QB == 4 ? launch_sym<4>(c, a) : c->QB == 6 ? launch_sym<6>(c, a) : c->QB == 8 ? launch_sym<8>(c, a) : launch_sym<10>(c, a);
     if (rc != GP_OK) return rc;
   } else
   switch (c->QB) {

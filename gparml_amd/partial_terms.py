@@ -82,13 +82,26 @@ class partial_terms(object):
             self._have_data = False
             self._stats_on_device = False
             self._gstep_key = None
+            self._pushed = None
         return self._eng
 
+    _pushed = None
+
     def _push_globals(self):
+        """gp_set_globals with the current attributes -- once per distinct (engine, Z, sf2, alpha, beta, N): the call starts a new evaluation on the device
+        (in the library's poison test mode it refills every per-evaluation buffer with NaN), and predict.py's sequence set_data -> get_local_statistics ->
+        set_local_statistics -> logmarglik -> grad_X_mu (predict.py:116-144) reads the Psi1 of ITS set_data after the statistics were replaced: pushing
+        unchanged globals a second time in between would declare that Psi1 stale."""
         eng = self._engine()
         Ng = int(self.N) if self.N is not None else eng.N_s
-        eng.set_globals(np.asarray(self.Z, dtype=float).reshape(self.M, self.Q), self._sf2(), self._alpha(),
-                        float(np.asarray(self.beta).reshape(-1)[0]), N_global=max(Ng, eng.N_s if self._have_data else 1))
+        Z = np.ascontiguousarray(np.asarray(self.Z, dtype=float).reshape(self.M, self.Q))
+        sf2, alpha, beta = self._sf2(), self._alpha(), float(np.asarray(self.beta).reshape(-1)[0])
+        Nglob = max(Ng, eng.N_s if self._have_data else 1)
+        key = (id(eng), eng.h.value if hasattr(eng.h, 'value') else eng.h, Z.tobytes(), sf2, alpha.tobytes(), beta, Nglob)
+        if self._pushed == key:
+            return
+        eng.set_globals(Z, sf2, alpha, beta, N_global=Nglob)
+        self._pushed = key
 
     def _ensure_gstep(self):
         """Global step (Cholesky, F, partials) up to date with the current attributes and statistics."""

@@ -26,7 +26,7 @@ assert lib.gp_debug_set_option(b'poison_alloc', 1) == 0
 # (N, D, M, Q, regime, alpha, embedding gradients): fast fixed-embedding path, general phase 2, free embeddings on every phase-2 kernel family
 # (column kernel, tile pairs on the VALU, tile pairs on the matrix core with 2 launches, the generic wide-latent kernel), ragged sizes, M = 1
 SHAPES = [(4096, 100, 512, 10, 'A', 0.3, False), (2000, 10, 128, 13, 'A', 0.2, True), (1000, 7, 130, 10, 'B', 0.3, True), (600, 3, 512, 10, 'B', 0.3, True),
-          (640, 3, 33, 13, 'B', 0.2, True), (9000, 3, 200, 20, 'B', 0.1, True), (300, 2, 40, 30, 'B', 0.08, True), (150, 2, 12, 60, 'B', 0.05, True),
+          (640, 3, 33, 13, 'B', 0.2, True), (9000, 3, 200, 20, 'B', 0.1, True), (300, 2, 40, 30, 'B', 0.08, True), (150, 2, 12, 70, 'B', 0.05, True),
           (257, 2, 1, 1, 'B', 1.0, True), (129, 1, 1, 1, 'A', 1.0, False)]
 for (N, D, M, Q, regime, alpha, emb) in SHAPES:
     d = Fz.synthetic_shard(N, D, M, Q, regime=regime, seed=11, zseed=12, alpha_value=alpha)
@@ -38,7 +38,8 @@ for (N, D, M, Q, regime, alpha, emb) in SHAPES:
         eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
         outs.append(eng.evaluate(emb))
     eng.close()
-    keys = ['grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'] + (['grad_X_mu', 'grad_X_S'] if emb else [])
+    # (fixed variances: the reference's grad_X_S divides by S = 0, partial_terms.py:400-431 -- not compared, as in tests/test_gpu_parity.py)
+    keys = ['grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'] + (['grad_X_mu'] if emb else []) + (['grad_X_S'] if emb and regime == 'B' else [])
     for out in outs:
         assert np.isfinite(out['F']) and abs(out['F'] - ref['F']) <= 1e-6 * abs(ref['F']), ((N, D, M, Q, regime), out['F'], ref['F'])
         for k in keys:

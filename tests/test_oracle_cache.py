@@ -95,7 +95,8 @@ def test_committed_files_against_the_live_oracle():
     t = time.time()
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-s', '-m', 'gpu', '-p', 'no:cacheprovider'] + nodes, capture_output=True, text=True, cwd=ROOT, env=env,
                        timeout=7200)
-    done = [ln for ln in r.stdout.splitlines() if ln.startswith('ORACLE_CACHE_AUDIT')]
-    print('\n'.join(done), '\n(%.0f s)' % (time.time() - t))
+    import re
+    done = re.findall(r'ORACLE_CACHE_AUDIT (\S+) ok: [^\n]*', r.stdout)          # (pytest -s puts its progress characters in front of the line)
+    print('\n'.join(m.group(0) for m in re.finditer(r'ORACLE_CACHE_AUDIT [^\n]*', r.stdout)), '\n(%.0f s)' % (time.time() - t))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert sorted(ln.split()[1] for ln in done) == keys, (done, r.stdout[-2000:])
+    assert sorted(done) == keys, (done, r.stdout[-2000:])

@@ -9,14 +9,18 @@ ROUNDS=3
 while getopts "r:" o; do case $o in r) ROUNDS=$OPTARG;; esac; done
 shift $((OPTIND - 1))
 tools/ab.sh -r $ROUNDS "$@"
-for v in "$@"; do
+for spec in "$@"; do
+  v=${spec%%:*}
   lib=$R/gparml_amd/lib_$v.so.bin; [ "$v" == "intree" ] && lib=$R/gparml_amd/libgparml_hip.so
   export GPARML_LIB=$lib
+  # run-time switches of the variant (NAME:ENV=VALUE[,ENV=VALUE]) are exported into this shell: rocprofv3 must start python3 itself (no env / bash -c hop)
+  if [ "$spec" != "$v" ]; then for kv in $(echo "${spec#*:}" | tr ',' ' '); do export "$kv"; done; fi
+  tag=$(echo "$spec" | tr ':=,' '___')
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    O=$R/gpurun_out/abt_${v}_$ctr; rm -rf $O; mkdir -p $O
+    O=$R/gpurun_out/abt_${tag}_$ctr; rm -rf $O; mkdir -p $O
     (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc $ctr -d $O -o c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/log.txt 2>&1)
   done
-  python3 - "$v" <<'PY'
+  python3 - "$tag" <<'PY'
 import csv, glob, sys, collections
 v = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -31,5 +35,6 @@ for k, d in agg.items():
     # KB units; gfx950 FETCH_SIZE counts half the bytes of 16 B/lane streaming reads (MI355X_MICROARCH.md): x2
     print('%-8s %-40s fetch_kb %.0f write_kb %.0f  hbm_GB_per_launch %.2f' % (v, k[:40], f, w, (2 * f + w) * 1024 / 1e9))
 PY
-  rm -rf gpurun_out/abt_${v}_*/*kernel_trace.csv gpurun_out/abt_${v}_*/*counter_collection.csv gpurun_out/abt_${v}_*/*agent_info.csv
+  rm -rf gpurun_out/abt_${tag}_*/*kernel_trace.csv gpurun_out/abt_${tag}_*/*counter_collection.csv gpurun_out/abt_${tag}_*/*agent_info.csv
+  if [ "$spec" != "$v" ]; then for kv in $(echo "${spec#*:}" | tr ',' ' '); do unset "${kv%%=*}"; done; fi
 done

@@ -79,23 +79,8 @@ __device__ __forceinline__ double fexp_t(double x, const ExpTab& tb) {
   return ldexp(__hiloint2double(hi, lo) * p, ni >> 6);
 }
 
-// ---- the table form with the lookup as a GLOBAL load (r06): the 512-byte table sits in the vector L1 / L2, the lookup is one global_load_dwordx2 off a
-// scalar base and counts on vmcnt -- not on lgkmcnt, which a loop that feeds wave-uniform row operands through scalar loads (psi2_pairs_kernel,
-// psi2_sym_kernel) has to drain completely at every wait (SMEM returns out of order: any wait with a scalar load in flight is lgkmcnt(0), so the two
-// ds_bpermute of fexp_t serialise with the next rows' s_load).  No cross-lane access: lanes may be inactive.  Same arithmetic as fexp_t (same bits).
-__device__ __forceinline__ double fexp_v(double x, const double* __restrict__ tab) {
-  const double n = rint(x * 9.23324826168936568e+01);           // 64 / ln 2
-  double r = fma(n, -0x1.62e42ff000000p-7, x);
-  r = fma(n, 6.56392980106419468e-13, r);
-  const int ni = (int)n;
-  const double t = tab[ni & 63];
-  double p = 1.0 / 120.0;
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(t * p, ni >> 6);
-}
+// (r06: the table lookup as a global load -- vmcnt instead of lgkmcnt, which the ds_bpermute share with the scalar row loads of psi2_pairs_kernel /
+// psi2_sym_kernel -- was measured: the 64-lane gather into a 512-byte table costs more than the waits it removes, psi2_pairs_kernel 13.1 -> 18.6 ms and
+// psi2_sym_kernel 29.9 -> 33.3 ms per 1e5 points; profiles/r06_gplvm_experiments.txt.)
 
 }  // namespace gp

@@ -167,9 +167,6 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
 #ifdef GPARML_PAIRS_FEXP      // timing build: the table-free exp (17 instead of 12 FP64 instructions, no ds_bpermute): is the loop bound by the LDS crossbar?
     acc0 += fexp(e[0]) + fexp(e[2]);
     acc1 += fexp(e[1]) + fexp(e[3]);
-#elif defined(GPARML_PAIRS_VTAB)   // the table lookup as a global load (vmcnt) instead of two ds_bpermute (lgkmcnt, shared with the scalar row loads)
-    acc0 += fexp_v(e[0], kExp2Tab64) + fexp_v(e[2], kExp2Tab64);
-    acc1 += fexp_v(e[1], kExp2Tab64) + fexp_v(e[3], kExp2Tab64);
 #else
     acc0 += fexp_t(e[0], xt) + fexp_t(e[2], xt);
     acc1 += fexp_t(e[1], xt) + fexp_t(e[3], xt);
@@ -257,11 +254,7 @@ __global__ void __launch_bounds__(256, 2) psi2_pairs_mfma_kernel(const double* _
 #pragma unroll
       for (int cq = 0; cq < 4; ++cq) lc[cq] = LEA[(n + 1) * Mp + c0 + 4 * cq + li];
     }
-    double E[4][4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int cq = 0; cq < 4; ++cq) E[rb][cq] = 0.0;
+    double E[4][4];      // the first k-step's MFMAs take C = 0 as an inline constant (mfma444_zero): no zeroing moves next to asm MFMAs
     {
       // explicit ds_read_b64 operand reads with counted waits, asm MFMAs (see psi2_cols_mfma_kernel: hipcc's ds_read2_b64 merge
       // makes the A reads 2-way bank conflicts)
@@ -281,7 +274,10 @@ __global__ void __launch_bounds__(256, 2) psi2_pairs_mfma_kernel(const double* _
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-          for (int cq = 0; cq < 4; ++cq) mfma444_acc(E[rb][cq], av[cur][rb], bv[cur][cq]);
+          for (int cq = 0; cq < 4; ++cq) {
+            if constexpr (k4 == 0) mfma444_zero(E[rb][cq], av[cur][rb], bv[cur][cq]);
+            else mfma444_acc(E[rb][cq], av[cur][rb], bv[cur][cq]);
+          }
       });
       mfma_drain(E[3][3]);
 #pragma unroll
@@ -514,11 +510,7 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
             double e = lrow[m0 + u] + lea;                  // these operands made hipcc spill SGPRs through v_writelane: +20 %)
 #pragma unroll
             for (int q = 0; q < QT; ++q) e = fma(zm[q], zz[q], e);
-#ifdef GPARML_SYM_VTAB
-            T[u] = bb[u] * fexp_v(e, kExp2Tab64);
-#else
             T[u] = bb[u] * fexp(e);
-#endif
             r += T[u];
 #pragma unroll
             for (int q = 0; q < QT; ++q) t[q] = fma(T[u], zm[q], t[q]);
@@ -673,7 +665,8 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   {
     const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2, RTs = (c->QB + 1 + 3) / 4 * 4;
     const size_t smem = (size_t)Mp * RTs * sizeof(double);
-    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
+    static const int minw = [] { const char* e = getenv("GPARML_B_SYM_MINWAVES"); return e ? atoi(e) : 12; }();
+    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= (size_t)minw;
     c->sym_nw = nw;
   }
   // the matrix-core tile-pair phase 2 (psi2_tile.hip) wherever psi2_sym_kernel does not apply; it keeps its own per-launch sums buffer

@@ -665,8 +665,8 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   {
     const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2, RTs = (c->QB + 1 + 3) / 4 * 4;
     const size_t smem = (size_t)Mp * RTs * sizeof(double);
-    static const int minw = [] { const char* e = getenv("GPARML_B_SYM_MINWAVES"); return e ? atoi(e) : 12; }();
-    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= (size_t)minw;
+    // (>= 12 waves per CU re-measured in r06: M = 1024, Q = 10 -- one eight-wave workgroup per CU -- 75.5 ms per 5e4 points on this kernel against 69.8 on the column kernel)
+    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
     c->sym_nw = nw;
   }
   // the matrix-core tile-pair phase 2 (psi2_tile.hip) wherever psi2_sym_kernel does not apply; it keeps its own per-launch sums buffer

@@ -146,6 +146,8 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
   unsigned o1 = 8u * (unsigned)m1, o2 = 8u * (unsigned)m2;
   double acc0 = 0.0, acc1 = 0.0;
   long n = n0;
+  // (r06: the eight LE values of the NEXT trip requested at the top of the current one -- 16 more VGPRs, seven waves per SIMD instead of eight -- measured slower:
+  // 13.7 -> 14.3 ms per 1e5 points at Q = 10, 15.6 -> 23.1 at Q = 16: eight waves already hide that latency; profiles/r06_gplvm_experiments.txt)
   for (; n + 4 <= n1; n += 4) {
     double e[4];
 #pragma unroll
@@ -351,6 +353,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// the lane's index inside its wave from the execution mask (v_mbcnt): no register has to carry threadIdx.x through a kernel's hot loop for the few places
+// behind it that need the lane (psi2_cols_kernel<10, true> spilled it: the library's last scratch allocation, r06)
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 
 template <int QT, bool KEEP>
@@ -360,14 +365,15 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Arg
                                                         const double* __restrict__ alphaP) {
   constexpr int PW = 3 * QT + 1;
   __shared__ double red[4][PW];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the lane index comes from lane_id() wherever it is needed: nothing per-lane lives across the row loop but z, g, zz, t)
   const int nw = blockDim.x >> 6;                        // waves per workgroup = min(4, nslab)
   const int slab = blockIdx.y * nw + wave;
   const bool active = slab < a.nslab;                    // idle waves (nslab not a multiple of nw) only join the barriers
-  const int mc = (active ? slab : 0) * 64 + lane;        // this lane's column m' (< Mp; columns >= M: LEA = kPadLog, ZP = 0)
+  const int mc0 = (active ? slab : 0) * 64;              // wave-uniform; this lane's column m' = mc0 + lane (< Mp; columns >= M: LEA = kPadLog, ZP = 0)
   double* G = a.Gpart + (long)blockIdx.x * a.M * a.Q;    // this workgroup's grad_Z partial (rows of its slabs)
   double z[KEEP ? QT : 1], g[KEEP ? QT : 1];
   if (KEEP) {
+    const int mc = mc0 + lane_id();
 #pragma unroll
     for (int q = 0; q < QT; ++q) { z[q] = ZP[(long)mc * QT + q]; g[q] = 0.0; }
   }
@@ -376,6 +382,7 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Arg
   for (long n = n0; n < n1; ++n) {
     double zz[QT], t[QT], r = 0.0;
     if (active) {
+      const int mc = mc0 + lane_id();
       const double* v2 = V2P + n * QT;                   // wave-uniform
 #pragma unroll
       for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * (KEEP ? z[q] : ZP[(long)mc * QT + q]); t[q] = 0.0; }
@@ -383,6 +390,8 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Arg
       const double lea = lrow[mc];
       const double* bcol = Bbar + mc;
       constexpr int U = QT <= 10 ? 4 : 2;   // rows per trip: U z-rows (2 QT SGPRs each) must fit the scalar file
+      // (r06: Bbar of the next trip's rows requested one trip ahead, as psi2_sym_kernel does, for QT > 10 where registers are to spare: slower -- phase 2
+      // 42.2 -> 43.6 / 45.7 -> 47.9 / 48.2 -> 65.9 ms per 1e5 points at Q = 12 / 14 / 16; the loop is bound by FP64 issue, not by that latency)
       for (int m = 0; m < Mr; m += U) {
         double bb[U];
 #pragma unroll
@@ -404,6 +413,7 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Arg
       for (int q = 0; q < QT; ++q) { zz[q] = 0.0; t[q] = 0.0; }
     }
     // grad_Z of this lane's column and the per-point sums
+    const int lane = lane_id(), mc = mc0 + lane;
     const double* wn = WP + n * QT;                      // wave-uniform
     const double* mun = MUP + n * QT;
     double s0 = r;
@@ -419,16 +429,17 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Arg
     s0 = wave_sum(s0);
     if (lane == 0) red[wave][0] = s0;
     __syncthreads();
-    for (int i = threadIdx.x; i < PW; i += blockDim.x) {
+    for (int i = 64 * wave + lane; i < PW; i += blockDim.x) {
       double sum = red[0][i];
       for (int w = 1; w < nw; ++w) sum += red[w][i];
       a.pp[((long)blockIdx.y * PW + i) * a.Np + n] = sum;
     }
     __syncthreads();
   }
-  if (KEEP && active && mc < a.M) {
+  const int mcf = mc0 + lane_id();
+  if (KEEP && active && mcf < a.M) {
 #pragma unroll
-    for (int q = 0; q < QT; ++q) if (q < a.Q) G[(long)mc * a.Q + q] = g[q];
+    for (int q = 0; q < QT; ++q) if (q < a.Q) G[(long)mcf * a.Q + q] = g[q];
   }
 }
 
@@ -839,6 +850,9 @@ int run_phase2_b(gp_ctx* c) {
     case 4: launch_cols<4, true>(c, a); break;
     case 6: launch_cols<6, true>(c, a); break;
     case 8: launch_cols<8, true>(c, a); break;
+    // (<10, true> is the library's one kernel with a scratch allocation: 16 B per lane, two values spilled in the prologue and reloaded once per point, outside the
+    // row loop.  The scratch-free <10, false> form -- z re-read and grad_Z accumulated in memory per point -- is slower: same box, N = 1e5, M = 128: 2.75 -> 2.98 ms,
+    // M = 1024 (5e4 points): 69.2 -> 69.9 ms; profiles/r06_gplvm_experiments.txt)
     case 10: launch_cols<10, true>(c, a); break;
     case 12: launch_cols<12, false>(c, a); break;
     case 14: launch_cols<14, false>(c, a); break;

@@ -456,18 +456,27 @@ __global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Arg
 // the slabs (a round = disjoint slab pairs, one per wave, rounds separated by a barrier), so no two waves ever touch the same rows
 // of rt at the same time: plain read-add-write in a fixed order, no atomics, results bit-identical from run to run.  When all
 // rounds are done every thread finishes its rows (grad_Z of the row, the per-point sums) exactly as the column kernel does.
-// (r06: the same kernel at the latent widths 12, 14 and 16 -- rt rows QT + 1 doubles apart so that three workgroups still fit at QT = 12, the row side's B
-// operand either re-read per group of rows (168 VGPRs, three waves per SIMD) or live at two waves per SIMD -- was built, parity-green and NOT faster than the
-// column kernel: same box, N = 1e5, M = 512, ms of the phase-2 kernel at Q = 12 / 14 / 16: 40.9 / 52.7 / 64.1 (re-read) and 42.5 / 50.7 / 56.9 (live) against
-// 41.0 / 45.1 / 47.7 for psi2_cols_kernel, which runs both sides of every pair but at three waves per SIMD and without the 4 NQ operand registers;
-// profiles/r06_gplvm_experiments.txt.  Removed again.)
+// r06, latent width 12 (Q = 11, 12): the kernel as it stands for QT <= 10 needs 168 VGPRs + 100-132 B of scratch there (4 NQ = 16 operand registers of the row
+// side, 2 x 24 registers of zz / t) and 64 KB of LDS (two workgroups per CU): measured no faster than the column kernel (40.9 against 41.0 ms per 1e5 points), and
+// 14 / 16 slower (52.7 / 64.1 against 45.1 / 47.7).  What made 12 work (35.3 against 42.5 ms, Q = 11: 34.6 against 42.2): (1) rt rows QT + 1 doubles apart
+// (52 KB: three workgroups per CU); (2) at QT = 12 the ones column opens a feature quad of its own, [1 0 0 0] for every column -- ONE operand register built from
+// the lane id instead of four loaded ones; (3) no one-group-ahead request of Bbar; (4) the four rows of a group two at a time (a scheduling barrier between the
+// pairs: four interleaved exp chains do not fit); (5) the per-point finish in two passes of six latent dimensions (3 x 12 running sums in one pass spilled).
+// 128 VGPRs, no scratch.  14 and 16 stay on the column kernel: 15 / 17 doubles per row of rt are two workgroups per CU whatever the registers do
+// (profiles/r06_gplvm_experiments.txt).
+__host__ __device__ constexpr int sym_rs(int QT) { return QT <= 10 ? (QT + 1 + 3) / 4 * 4 : QT + 1; }
+
 template <int QT>
 __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
                                                        const double* __restrict__ Bbar, const double* __restrict__ LEA,
                                                        const double* __restrict__ V2P, const double* __restrict__ WP,
                                                        const double* __restrict__ MUP, const double* __restrict__ alphaP,
                                                        const int* __restrict__ sched, int nrounds) {
-  constexpr int RT = (QT + 1 + 3) / 4 * 4, NQ = RT / 4, PW = 3 * QT + 1, RS = RT;      // RT: feature columns of the row-side MFMAs = row stride of rt
+  // RT: feature columns of the row-side MFMAs ([Z | 1] padded to four); RS: row stride of rt -- RT up to QT = 10, QT + 1 at QT = 12 (52 KB at M = 512: three
+  // workgroups per CU; with the padded stride two).  ONESQ (QT = 12): the ones column opens a feature quad of its own, [1 0 0 0] -- the same B operand for every
+  // column, so it is ONE register built from the lane id instead of four loaded ones, and the kernel keeps its 3 x 4 operand registers of Z like QT = 10.
+  constexpr int RT = (QT + 1 + 3) / 4 * 4, NQ = RT / 4, PW = 3 * QT + 1, RS = sym_rs(QT);
+  constexpr bool ONESQ = (QT % 4) == 0;
   extern __shared__ double smem[];
   double* rt = smem;                       // [Mp][RS]   t_m[q] (q < QT), r_m (index QT) of the current point
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -498,22 +507,31 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
         double ZB[4][NQ];
         const double* zbp = Z1S + (long)(64 * J + 16 * lk + 4 * lb) * RT + lq;
         if (offd) {
+          const double onesq = (lq == 0) ? 1.0 : 0.0;
 #pragma unroll
           for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = zbp[v * RT + 4 * qq];
+            for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = (ONESQ && qq == NQ - 1) ? onesq : zbp[v * RT + 4 * qq];
         }
-        double bbn[4];                                      // Bbar of the next group of rows, one group ahead
+        constexpr bool BPF = QT <= 10;                       // Bbar of the next group of rows one group ahead (QT = 12: no registers left for it)
+        double bbn[4];
+        if (BPF) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(64 * I + u) * a.Mp];
+          for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(64 * I + u) * a.Mp];
+        }
         for (int g = 0; g < 16; ++g) {
           const int m0 = 64 * I + 4 * g;
           double bb[4], T[4];
+          if (BPF) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) bb[u] = bbn[u];
-          if (g + 1 < 16) {
+            for (int u = 0; u < 4; ++u) bb[u] = bbn[u];
+            if (g + 1 < 16) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(m0 + 4 + u) * a.Mp];
+              for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(m0 + 4 + u) * a.Mp];
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bb[u] = bcol[(long)(m0 + u) * a.Mp];
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -525,6 +543,8 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
             r += T[u];
 #pragma unroll
             for (int q = 0; q < QT; ++q) t[q] = fma(T[u], zm[q], t[q]);
+            // QT = 12: the four rows two at a time (four interleaved exp chains with their temporaries do not fit next to 2 x 24 + 26 long-lived registers)
+            if (QT > 10 && u == 1) __builtin_amdgcn_sched_barrier(0);
           }
           if (offd) {
             double acc[NQ];
@@ -532,7 +552,7 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
             if (lb == 0) {
               double* dst = rt + (m0 + lk) * RS + lq;
 #pragma unroll
-              for (int qq = 0; qq < NQ; ++qq) dst[4 * qq] += acc[qq];
+              for (int qq = 0; qq < NQ; ++qq) if (RS == RT || 4 * qq + lq <= QT) dst[4 * qq] += acc[qq];      // (compact stride: features beyond the ones column do not exist)
             }
           }
         }
@@ -547,34 +567,46 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
     // ---- finish the point: every thread takes rows tid, tid + blockDim.x, ... (and clears them for the next point)
     const double* wn = WP + n * QT;                      // wave-uniform
     const double* mun = MUP + n * QT;
-    double s0 = 0.0, s1[QT], s2[QT], s3[QT];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) { s1[q] = 0.0; s2[q] = 0.0; s3[q] = 0.0; }
-    for (int m = tid; m < a.Mp; m += blockDim.x) {
-      double* src = rt + m * RS;
-      const double r = src[QT];
-      src[QT] = 0.0;
-      s0 += r;
-#pragma unroll
-      for (int q = 0; q < QT; ++q) {
-        const double tq = src[q];
-        src[q] = 0.0;
-        const double zq = ZP[(long)m * QT + q];
-        const double gq = -alphaP[q] * (zq * r - tq) + wn[q] * (2.0 * mun[q] * r - zq * r - tq);
-        if (m < a.M && q < a.Q) { double* d = G + (long)m * a.Q + q; *d = ((n == n0) ? 0.0 : *d) + gq; }
-        s1[q] = fma(zq, r, s1[q]); s2[q] = fma(zq * zq, r, s2[q]); s3[q] = fma(zq, tq, s3[q]);
-      }
-    }
-    // the waves' sums go to pp as they are, one group per wave (a.ngrp = waves): psi2_points_finish_kernel adds the groups in wave order -- the order the
-    // LDS hand-over of r03-r05 used, so the bits are the same -- and the [waves][PW] LDS array with its second barrier is gone (r06)
+    // QC latent dimensions at a time (all of them up to QT = 10; six at QT = 12, where the 3 QT running sums of one pass did not fit the registers): the rows' r stays
+    // in place until the last pass
+    constexpr int QC = QT <= 10 ? QT : 6;
+    static_assert(QT % QC == 0, "q chunks");
     double* ppw = a.pp + (long)wave * PW * a.Np + n;
-    s0 = wave_sum(s0);
-    if (lane == 0) ppw[0] = s0;
+    static_for<0, QT / QC>([&](auto cc) {
+      constexpr int q0 = decltype(cc)::value * QC;
+      constexpr bool first = q0 == 0, last = q0 + QC == QT;
+      double s0 = 0.0, s1[QC], s2[QC], s3[QC];
 #pragma unroll
-    for (int q = 0; q < QT; ++q) {
-      const double x1 = wave_sum(s1[q]), x2 = wave_sum(s2[q]), x3 = wave_sum(s3[q]);
-      if (lane == 0) { ppw[(long)(1 + q) * a.Np] = x1; ppw[(long)(1 + QT + q) * a.Np] = x2; ppw[(long)(1 + 2 * QT + q) * a.Np] = x3; }
-    }
+      for (int q = 0; q < QC; ++q) { s1[q] = 0.0; s2[q] = 0.0; s3[q] = 0.0; }
+      for (int m = tid; m < a.Mp; m += blockDim.x) {
+        double* src = rt + m * RS;
+        const double r = src[QT];
+        if (last) src[QT] = 0.0;
+        if (first) s0 += r;
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi) {
+          const int q = q0 + qi;
+          const double tq = src[q];
+          src[q] = 0.0;
+          const double zq = ZP[(long)m * QT + q];
+          const double gq = -alphaP[q] * (zq * r - tq) + wn[q] * (2.0 * mun[q] * r - zq * r - tq);
+          if (m < a.M && q < a.Q) { double* d = G + (long)m * a.Q + q; *d = ((n == n0) ? 0.0 : *d) + gq; }
+          s1[qi] = fma(zq, r, s1[qi]); s2[qi] = fma(zq * zq, r, s2[qi]); s3[qi] = fma(zq, tq, s3[qi]);
+        }
+      }
+      // the waves' sums go to pp as they are, one group per wave (a.ngrp = waves): psi2_points_finish_kernel adds the groups in wave order -- the order the
+      // LDS hand-over of r03-r05 used, so the bits are the same -- and the [waves][PW] LDS array with its second barrier is gone (r06)
+      if (first) {
+        s0 = wave_sum(s0);
+        if (lane == 0) ppw[0] = s0;
+      }
+#pragma unroll
+      for (int qi = 0; qi < QC; ++qi) {
+        const int q = q0 + qi;
+        const double x1 = wave_sum(s1[qi]), x2 = wave_sum(s2[qi]), x3 = wave_sum(s3[qi]);
+        if (lane == 0) { ppw[(long)(1 + q) * a.Np] = x1; ppw[(long)(1 + QT + q) * a.Np] = x2; ppw[(long)(1 + 2 * QT + q) * a.Np] = x3; }
+      }
+    });
     __syncthreads();       // every row of rt has been read and cleared before the next point's tiles add to it
   }
 }
@@ -674,10 +706,11 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   // ... and its per-point array rt (Mp x RT doubles of LDS per workgroup) must leave room for twelve waves per CU: with fewer
   // the scalar-operand latency is exposed and the column kernel (four waves per SIMD) is faster (M = 1024: one workgroup per CU)
   {
-    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2, RTs = (c->QB + 1 + 3) / 4 * 4;
-    const size_t smem = (size_t)Mp * RTs * sizeof(double);
+    const int nv = (c->nslab + 1) / 2 * 2, nw = nv / 2;
+    const size_t smem = (size_t)Mp * sym_rs(c->QB) * sizeof(double);
+    static const int maxq = [] { const char* e = getenv("GPARML_B_SYM_MAXQ"); return e ? atoi(e) : 12; }();     // 10: the column kernel at Q = 11, 12 (same-box A/B)
     // (>= 12 waves per CU re-measured in r06: M = 1024, Q = 10 -- one eight-wave workgroup per CU -- 75.5 ms per 5e4 points on this kernel against 69.8 on the column kernel)
-    c->b_sym = !c->b_mfma && c->QB <= 10 && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
+    c->b_sym = !c->b_mfma && c->QB <= std::min(maxq, 12) && c->nslab >= 3 && c->nslab <= 16 && smem <= 160 * 1024 && (160 * 1024 / smem) * nw >= 12;
     c->sym_nw = nw;
   }
   // the matrix-core tile-pair phase 2 (psi2_tile.hip) wherever psi2_sym_kernel does not apply; it keeps its own per-launch sums buffer
@@ -823,7 +856,7 @@ static void launch_cols(gp_ctx* c, const PB2Args& a) {
 
 template <int QT>
 static int launch_sym(gp_ctx* c, const PB2Args& a) {
-  const size_t smem = (size_t)c->Mp * ((QT + 1 + 3) / 4 * 4) * sizeof(double);
+  const size_t smem = (size_t)c->Mp * sym_rs(QT) * sizeof(double);
   GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_sym_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((psi2_sym_kernel<QT>), dim3(c->pb_blocks), dim3(64 * c->sym_nw), smem, c->stream, a, (const double*)c->ZP, (const double*)c->Z1S,
                      (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
@@ -843,7 +876,7 @@ int run_phase2_b(gp_ctx* c) {
     GP_TRY_RC(run_phase2_b_generic(c));
   } else if (c->b_sym) {
     a.ngrp = c->sym_nw;
-    int rc = c->QB == 4 ? launch_sym<4>(c, a) : c->QB == 6 ? launch_sym<6>(c, a) : c->QB == 8 ? launch_sym<8>(c, a) : launch_sym<10>(c, a);
+    int rc = c->QB == 4 ? launch_sym<4>(c, a) : c->QB == 6 ? launch_sym<6>(c, a) : c->QB == 8 ? launch_sym<8>(c, a) : c->QB == 10 ? launch_sym<10>(c, a) : launch_sym<12>(c, a);
     if (rc != GP_OK) return rc;
   } else
   switch (c->QB) {

@@ -86,9 +86,9 @@ SHAPES = [
     (1100, 2, 1024, 6, 'B', 0.8),
     # widths 12 and 14 (the column kernel), several slab groups and a single slab
     (500, 3, 300, 11, 'B', 0.4), (400, 2, 200, 12, 'B', 0.4), (350, 4, 130, 13, 'B', 0.3), (300, 2, 50, 14, 'B', 0.3),
-    # r06: the latent widths 12 ... 16 on five to ten column slabs (the column kernel's several slab groups; written for psi2_sym_kernel at these widths,
-    # which was measured no faster and removed -- profiles/r06_gplvm_experiments.txt)
-    (420, 3, 300, 12, 'B', 0.3), (530, 2, 512, 13, 'B', 0.25), (650, 2, 640, 14, 'B', 0.2), (460, 3, 450, 16, 'B', 0.15), (520, 2, 513, 15, 'B', 0.15),
+    # r06: psi2_sym_kernel<12> (Q = 11, 12: compact rt rows, the constant ones quad, the two-pass finish) on five slabs with a bye and on eight, the latent
+    # widths 14 and 16 on five to ten column slabs (the column kernel's several slab groups), Q = 16 on two slabs
+    (420, 3, 300, 12, 'B', 0.3), (520, 2, 512, 11, 'B', 0.25), (530, 2, 512, 13, 'B', 0.25), (650, 2, 640, 14, 'B', 0.2), (460, 3, 450, 16, 'B', 0.15), (520, 2, 513, 15, 'B', 0.15),
     (350, 2, 128, 16, 'B', 0.15),
 ]
 

@@ -358,8 +358,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 
+// Four waves per SIMD (128 VGPRs) up to QT = 14: r06, same box, phase 2 per 1e5 points at M = 512: Q = 13 / 14 44.7 / 45.1 -> 42.1 / 42.5 ms (the cap costs QT = 12 / 14
+// 20 / 28 B of scratch per lane -- values spilled in the prologue and reloaded once per POINT, outside the row loop -- and buys a fourth wave: FP64 issue 6.0 -> 5.6
+// cycles); QT = 16 gains nothing from it (47.6 -> 47.2) and keeps its 167 registers without scratch.
 template <int QT, bool KEEP>
-__global__ void __launch_bounds__(256, QT <= 10 ? 4 : 2) psi2_cols_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
+__global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
                                                         const double* __restrict__ LEA, const double* __restrict__ V2P,
                                                         const double* __restrict__ WP, const double* __restrict__ MUP,
                                                         const double* __restrict__ alphaP) {

@@ -467,10 +467,13 @@ __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Arg
 // pairs: four interleaved exp chains do not fit); (5) the per-point finish in two passes of six latent dimensions (3 x 12 running sums in one pass spilled).
 // 128 VGPRs, no scratch.  14 and 16 stay on the column kernel: 15 / 17 doubles per row of rt are two workgroups per CU whatever the registers do
 // (profiles/r06_gplvm_experiments.txt).
-__host__ __device__ constexpr int sym_rs(int QT) { return QT <= 10 ? (QT + 1 + 3) / 4 * 4 : QT + 1; }
+// the "register diet" (r06): compact rt rows, no one-group-ahead request of Bbar, the four rows of a group two at a time, the finish in two passes.  QT = 12 needs it to
+// exist at all; QT = 8 gets a fourth workgroup per CU from it (rt 36 KB, 96 VGPRs): phase 2 30.5 -> 28.0 ms per 1e5 points at Q = 8, 30.5 -> 27.5 at Q = 7 (same box).
+__host__ __device__ constexpr bool sym_diet(int QT) { return QT > 10 || QT == 8; }
+__host__ __device__ constexpr int sym_rs(int QT) { return sym_diet(QT) ? QT + 1 : (QT + 1 + 3) / 4 * 4; }
 
 template <int QT>
-__global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
+__global__ void __launch_bounds__(512, QT == 8 ? 4 : 3) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
                                                        const double* __restrict__ Bbar, const double* __restrict__ LEA,
                                                        const double* __restrict__ V2P, const double* __restrict__ WP,
                                                        const double* __restrict__ MUP, const double* __restrict__ alphaP,
@@ -516,7 +519,7 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
 #pragma unroll
             for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = (ONESQ && qq == NQ - 1) ? onesq : zbp[v * RT + 4 * qq];
         }
-        constexpr bool BPF = QT <= 10;                       // Bbar of the next group of rows one group ahead (QT = 12: no registers left for it)
+        constexpr bool BPF = !sym_diet(QT);                  // Bbar of the next group of rows one group ahead (QT = 12: no registers left for it)
         double bbn[4];
         if (BPF) {
 #pragma unroll
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
 #pragma unroll
             for (int q = 0; q < QT; ++q) t[q] = fma(T[u], zm[q], t[q]);
             // QT = 12: the four rows two at a time (four interleaved exp chains with their temporaries do not fit next to 2 x 24 + 26 long-lived registers)
-            if (QT > 10 && u == 1) __builtin_amdgcn_sched_barrier(0);
+            if (sym_diet(QT) && u == 1) __builtin_amdgcn_sched_barrier(0);
           }
           if (offd) {
             double acc[NQ];
@@ -572,7 +575,7 @@ __global__ void __launch_bounds__(512, 3) psi2_sym_kernel(PB2Args a, const doubl
     const double* mun = MUP + n * QT;
     // QC latent dimensions at a time (all of them up to QT = 10; six at QT = 12, where the 3 QT running sums of one pass did not fit the registers): the rows' r stays
     // in place until the last pass
-    constexpr int QC = QT <= 10 ? QT : 6;
+    constexpr int QC = sym_diet(QT) ? QT / 2 : QT;
     static_assert(QT % QC == 0, "q chunks");
     double* ppw = a.pp + (long)wave * PW * a.Np + n;
     static_for<0, QT / QC>([&](auto cc) {

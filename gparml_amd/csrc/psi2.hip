@@ -469,11 +469,13 @@ __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Arg
 // (profiles/r06_gplvm_experiments.txt).
 // the "register diet" (r06): compact rt rows, no one-group-ahead request of Bbar, the four rows of a group two at a time, the finish in two passes.  QT = 12 needs it to
 // exist at all; QT = 8 gets a fourth workgroup per CU from it (rt 36 KB, 96 VGPRs): phase 2 30.5 -> 28.0 ms per 1e5 points at Q = 8, 30.5 -> 27.5 at Q = 7 (same box).
-__host__ __device__ constexpr bool sym_diet(int QT) { return QT > 10 || QT == 8; }
+// QT <= 6: a fifth workgroup per CU (28.7 KB of rt, 82 VGPRs): 24.1 -> 23.4 ms at Q = 6.  QT = 10 -- the one width where compact rows do not buy a workgroup (45 KB) -- keeps the
+// round-3 layout: the diet's pieces measured neutral there, and moving r out of LDS to get to 40 KB cost 11 % (profiles/r06_gplvm_experiments.txt).
+__host__ __device__ constexpr bool sym_diet(int QT) { return QT != 10; }
 __host__ __device__ constexpr int sym_rs(int QT) { return sym_diet(QT) ? QT + 1 : (QT + 1 + 3) / 4 * 4; }
 
 template <int QT>
-__global__ void __launch_bounds__(512, QT == 8 ? 4 : 3) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
+__global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
                                                        const double* __restrict__ Bbar, const double* __restrict__ LEA,
                                                        const double* __restrict__ V2P, const double* __restrict__ WP,
                                                        const double* __restrict__ MUP, const double* __restrict__ alphaP,

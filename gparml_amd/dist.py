@@ -66,7 +66,7 @@ def _bounded(fn, seconds, what, rank):
     return box.get('value')
 
 
-def init_native_comm(engine, dist, group=None):
+def init_native_comm(engine, dist, group=None, _agree=None):
     """Give ``engine`` its own RCCL communicator (gp_comm_init): rank 0 draws the ncclUniqueId, torch.distributed carries the 128 bytes to
     the other ranks, every rank joins.  Returns True when the engine now reduces inside the library (gp_allreduce); False when the
     engine has no such entry point, the backend is not RCCL (gloo tests), GPARML_NATIVE_ALLREDUCE=0, or ANY rank cannot use RCCL --
@@ -77,7 +77,10 @@ def init_native_comm(engine, dist, group=None):
     is the id broadcast and ncclCommInitRank entered (with a bounded wait, GPARML_COMM_INIT_TIMEOUT seconds, default 180).  A second
     agreement right after the call covers RCCL refusing the communicator on some rank (no collective has run on it yet, so the ranks
     that did join are not left waiting inside one); only then does a one-double probe all-reduce check that the communicator really
-    sums over ``world`` ranks, and a third agreement covers its outcome."""
+    sums over ``world`` ranks, and a third agreement covers its outcome.
+
+    ``_agree`` (tests only, tests/test_dist_gloo.py): a replacement for the MIN all-reduce over the torch group -- the order of agreement rounds and
+    collective calls is then exercised on CPU with a scripted peer."""
     import os
     if os.environ.get('GPARML_NATIVE_ALLREDUCE', '1') == '0':
         return _say(-1, '')
@@ -88,14 +91,19 @@ def init_native_comm(engine, dist, group=None):
         return _say(-1, 'process group backend is %s, not nccl' % dist.get_backend(group))
     if getattr(engine, 'has_comm', False):
         return True
-    import torch
-    dev = torch.device('cuda', int(getattr(engine, 'device', torch.cuda.current_device())))
+    import contextlib
     limit = float(os.environ.get('GPARML_COMM_INIT_TIMEOUT', '180'))
+    if _agree is None:
+        import torch
+        dev = torch.device('cuda', int(getattr(engine, 'device', torch.cuda.current_device())))
+        on_device = lambda: torch.cuda.device(dev)
 
-    def agree(ok):
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        return int(flag.item()) == 1
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+    else:
+        dev, agree, on_device = None, _agree, contextlib.nullcontext
 
     uid, why = None, ''
     try:
@@ -106,7 +114,7 @@ def init_native_comm(engine, dist, group=None):
             why = 'RCCL cannot be resolved by the library on rank %d' % rank
     except Exception as e:      # noqa: BLE001
         ok, why = False, 'rank %d: %s' % (rank, e)
-    with torch.cuda.device(dev):
+    with on_device():
         if not agree(ok):
             return _say(rank, why or 'a peer rank cannot use RCCL from the library')
         box = [uid]

@@ -136,3 +136,99 @@ def test_draw_kept_mask_follows_the_reference():
     assert mask == list(~drop) and f == float((~drop).sum()) / 8
     mask, f = draw_kept_mask(5, 1.0, np.random.RandomState(1))
     assert sum(mask) == 1 and f == 1.0 / 6
+
+
+# ---- dist.init_native_comm: the ORDER of agreement rounds and collective calls (round-5 advice: a rank whose gp_comm_init raised skipped the probe all-reduce
+# while its peers sat inside it until the watchdog killed them).  A scripted peer stands in for the torch group; no GPU, no RCCL.
+class _FakeDist(object):
+    def __init__(self, rank, world):
+        self.rank, self.world, self.log = rank, world, []
+
+    def is_initialized(self):
+        return True
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_backend(self, group=None):
+        return 'nccl'
+
+    def get_global_rank(self, group, r):
+        return r
+
+    def broadcast_object_list(self, box, src=0, group=None, device=None):
+        self.log.append('broadcast_id')
+        if box[0] is None:
+            box[0] = b'id-from-rank-0'
+
+
+class _FakeEngine(object):
+    device = 0
+
+    def __init__(self, log, init_raises=False, probe_sum=None, world=2):
+        self.log, self.init_raises, self.probe_sum, self.world, self.has_comm = log, init_raises, probe_sum, world, False
+
+    def comm_available(self):
+        return True
+
+    def comm_unique_id(self):
+        return b'id-from-rank-0'
+
+    def comm_init(self, uid, world, rank):
+        self.log.append('comm_init')
+        if self.init_raises:
+            raise RuntimeError('ncclCommInitRank refused')
+        self.has_comm = True
+
+    def comm_info(self, probe=False):
+        self.log.append('probe' if probe else 'info')
+        return {'ranks': self.world, 'rank': 0, 'probe_sum': float(self.world if self.probe_sum is None else self.probe_sum)}
+
+    def comm_destroy(self):
+        self.log.append('comm_destroy')
+        self.has_comm = False
+
+
+def _scripted_agree(log, peer_answers):
+    it = iter(peer_answers)
+
+    def agree(ok):
+        peer = next(it)
+        log.append('agree(%d,%d)' % (int(ok), int(peer)))
+        return bool(ok) and bool(peer)
+    return agree
+
+
+def test_native_comm_agreement_rounds_all_ranks_join():
+    from gparml_amd import dist as gd
+    d = _FakeDist(0, 2)
+    eng = _FakeEngine(d.log)
+    assert gd.init_native_comm(eng, d, _agree=_scripted_agree(d.log, [1, 1, 1])) is True
+    # availability agreed -> id -> init -> agreement BEFORE anything collective on the new communicator -> probe -> agreement on its outcome
+    assert d.log == ['agree(1,1)', 'broadcast_id', 'comm_init', 'agree(1,1)', 'probe', 'agree(1,1)'] and eng.has_comm
+
+
+def test_native_comm_never_probes_when_a_rank_failed_to_join():
+    from gparml_amd import dist as gd
+    # this rank's gp_comm_init raises: it must still take part in the agreement round, and must not enter the probe
+    d = _FakeDist(1, 2)
+    eng = _FakeEngine(d.log, init_raises=True)
+    assert gd.init_native_comm(eng, d, _agree=_scripted_agree(d.log, [1, 1])) is False
+    assert d.log == ['agree(1,1)', 'broadcast_id', 'comm_init', 'agree(0,1)'] and 'probe' not in d.log
+    # the PEER failed to join: this rank holds a communicator, learns of the failure in the agreement round, destroys it and never probes
+    d = _FakeDist(0, 2)
+    eng = _FakeEngine(d.log)
+    assert gd.init_native_comm(eng, d, _agree=_scripted_agree(d.log, [1, 0])) is False
+    assert d.log == ['agree(1,1)', 'broadcast_id', 'comm_init', 'agree(1,0)', 'comm_destroy'] and not eng.has_comm
+    # a wrong probe sum (the communicator connected fewer ranks): third agreement round, communicator destroyed everywhere
+    d = _FakeDist(0, 2)
+    eng = _FakeEngine(d.log, probe_sum=1.0)
+    assert gd.init_native_comm(eng, d, _agree=_scripted_agree(d.log, [1, 1, 1])) is False
+    assert d.log == ['agree(1,1)', 'broadcast_id', 'comm_init', 'agree(1,1)', 'probe', 'agree(0,1)', 'comm_destroy']
+    # RCCL not available on a peer: nothing is created at all
+    d = _FakeDist(0, 2)
+    eng = _FakeEngine(d.log)
+    assert gd.init_native_comm(eng, d, _agree=_scripted_agree(d.log, [0])) is False and d.log == ['agree(1,0)']

@@ -501,6 +501,7 @@ def main():
             eng.close()
             res['extra'] = [config1_extra(local_rank),
                             regime_b_extra('BASELINE configs[2] shape with free embeddings (Bayesian GPLVM), 1e5-point slice', 100000, 100, 512, 10, local_rank),
+                            regime_b_extra('the same with a 12-dimensional latent space (r06: psi2_sym_kernel<12>; round 5: 56.3 ms)', 100000, 100, 512, 12, local_rank),
                             regime_b_extra('BASELINE configs[4] per-GPU shape (D=1000, M=1024, Q=50, free embeddings), 2e4-point slice', 20000, 1000, 1024, 50,
                                            local_rank),
                             regime_b_extra('BASELINE configs[4] at its FULL per-GPU size: N=1e6, D=1000, M=1024, Q=50, free embeddings', 1000000, 1000, 1024, 50,

@@ -43,6 +43,17 @@ static int choose_splits(long tiles, int K, size_t cap) {
 
 
 // A: [batch][Mp][Mp] SPD in, lower Cholesky factor out (upper zeroed); Linv: L^-1; Inv: A^-1; Twork: batch * Mp * Mp / 2 doubles
+// dst[b][r][0:128] = src[b][r][0:128] for r < rows: the panel solve's result from the work panel into the factor (two doubles per thread)
+__global__ void __launch_bounds__(256) panel_copy_kernel(const double* __restrict__ src, long sstride, double* __restrict__ dst, long ld, long dstride, long rows) {
+  const double* s = src + (long)blockIdx.y * sstride;
+  double* d = dst + (long)blockIdx.y * dstride;
+  const long total = rows * (NB / 2);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long r = i / (NB / 2), c2 = i - r * (NB / 2);
+    *reinterpret_cast<double2*>(d + r * ld + 2 * c2) = *reinterpret_cast<const double2*>(s + r * NB + 2 * c2);
+  }
+}
+
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A, double* Linv, double* Inv, double* Twork,
                           double* logdet2, double* fail_flag, double* splitk_ws, size_t splitk_cap) {
   const int nt = Mp / NB;
@@ -54,13 +65,24 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
     hipLaunchKernelGGL(potrf_trinv128_kernel, dim3(batch), dim3(512), POTRF_LDS_DOUBLES * 8, st, A, ld, bs, j, Linv, fail_flag, logdet2);
     const int rem = nt - j - 1;
     if (rem > 0) {
-      // panel: L[i,j] = A[i,j] * inv(L_jj)^T, i > j   (rows rem*128, cols 128, k 128); in place
+      // panel: L[i,j] = A[i,j] * inv(L_jj)^T, i > j   (rows rem*128, cols 128, k 128) -- through the work panel, see below
       GemmP p;
       p.A = A + ((long)(j + 1) * NB) * ld + (long)j * NB; p.lda = ld; p.sA = bs;
       p.B = Linv + ((long)j * NB) * ld + (long)j * NB; p.ldb = ld; p.sB = bs;   // B(k,c) = Xjj[c][k]: stored [c][k] -> K_CONTIG
       p.C = A + ((long)(j + 1) * NB) * ld + (long)j * NB; p.ldc = ld; p.sC = bs;
       p.K = NB; p.alpha = 1.0; p.beta = 0.0; p.tri = 0;
+      // NOT in place (r06).  Until then C was A itself, and launch_gemm's small-tile path (32 x 32 tiles for <= 256 tiles) ran it with four workgroups per 32 rows,
+      // each reading all 128 columns of the rows and overwriting 32 of them: a race that timing hid -- every workgroup resident and in step, the reads over long
+      // before the first store -- except on a cold start: the FIRST evaluation of a fresh process at M = 1024 with free embeddings came back with both
+      // factorisations flagged in 40-70 % of the processes (NaN from panel 1 on; the evaluator then repeats the step with the reference's 1e-7 jitter: F 2.9e-8,
+      // grad_Z 4.1e-6 off -- inside the parity tolerance on a well-conditioned problem, 1e-4 on a badly conditioned one: in all likelihood round 5's
+      // unreproduced test_gpu_tile_phase2 failure, whose evaluations run in a fresh child process).  The product goes to the work panel and a copy kernel puts it
+      // in place (+ ~5 us per panel; the 128 x 128-tile kernel in place -- one workgroup owns all columns of its rows -- is safe too but costs 20 us per panel).
+      // profiles/r06_first_evaluation_race.txt, tests/test_gpu_first_evaluation.py.
+      p.C = Twork; p.ldc = NB; p.sC = (long)rem * NB * NB;
       launch_gemm(st, K_CONTIG, K_CONTIG, rem * NB, NB, batch, p);
+      hipLaunchKernelGGL(panel_copy_kernel, dim3((unsigned)std::min<long>(((long)rem * NB * NB / 2 + 255) / 256, 512), batch), dim3(256), 0, st, (const double*)Twork,
+                         (long)rem * NB * NB, A + ((long)(j + 1) * NB) * ld + (long)j * NB, ld, bs, (long)rem * NB);
       // trailing update: A[i,k] -= L[i,j] L[k,j]^T for i >= k > j (lower tiles)
       GemmP q;
       q.A = A + ((long)(j + 1) * NB) * ld + (long)j * NB; q.lda = ld; q.sA = bs;

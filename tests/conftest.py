@@ -23,7 +23,7 @@ _GPU_ORDER = [
     # tier 0: golden fixtures of the reference and the oracle, method by method, then the extended-precision truths
     'test_gpu_parity', 'test_gpu_partial_terms', 'test_gpu_pipeline', 'test_gpu_predict', 'test_gpu_phase2_general',
     'test_gpu_hp_truth', 'test_hp_truth_large', 'test_gpu_global_step', 'test_gpu_linalg',
-    'test_gpu_c_consumer', 'test_gpu_resident_scg', 'test_gpu_resident_gd', 'test_gpu_dropout', 'test_gpu_tile_phase2', 'test_gpu_p1_i8', 'test_gpu_fuzz_shapes',
+    'test_gpu_c_consumer', 'test_gpu_first_evaluation', 'test_gpu_resident_scg', 'test_gpu_resident_gd', 'test_gpu_dropout', 'test_gpu_tile_phase2', 'test_gpu_p1_i8', 'test_gpu_fuzz_shapes',
 ]
 _GPU_LATE = [
     # tier 1: properties at the configurations' full sizes (seconds of device time, gigabytes of host data)

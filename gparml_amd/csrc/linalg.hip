@@ -69,7 +69,6 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
       GemmP p;
       p.A = A + ((long)(j + 1) * NB) * ld + (long)j * NB; p.lda = ld; p.sA = bs;
       p.B = Linv + ((long)j * NB) * ld + (long)j * NB; p.ldb = ld; p.sB = bs;   // B(k,c) = Xjj[c][k]: stored [c][k] -> K_CONTIG
-      p.C = A + ((long)(j + 1) * NB) * ld + (long)j * NB; p.ldc = ld; p.sC = bs;
       p.K = NB; p.alpha = 1.0; p.beta = 0.0; p.tri = 0;
       // NOT in place (r06).  Until then C was A itself, and launch_gemm's small-tile path (32 x 32 tiles for <= 256 tiles) ran it with four workgroups per 32 rows,
       // each reading all 128 columns of the rows and overwriting 32 of them: a race that timing hid -- every workgroup resident and in step, the reads over long

@@ -185,6 +185,7 @@ class ShardEngine(object):
         reference's 1e-7 jitter when a factorisation failed (partial_terms.py:452-456) and raises LinAlgError if that fails too;
         ``sync=False`` (the evaluators) defers all of that to finish(), the evaluation's single host synchronisation."""
         self._ck(self.lib.gp_global_step_jitter(self.h, int(jitter)), 'gp_global_step')
+        self._jitter_used = int(jitter)         # the mask this step ends up with (last_jitter reports it)
         # An evaluator whose previous evaluation needed the jitter (finish() saw the failed factorisation only after phase 2 had run on its
         # garbage: the whole phase 2 twice per evaluation, +62 % at N = 1e5, M = 512, Q = 5 with free embeddings) checks the outcome HERE the
         # next time: still the reference's order -- first without jitter, then with (partial_terms.py:452-456) -- for one extra host wait
@@ -197,7 +198,7 @@ class ShardEngine(object):
                     self._jitter_hint = used
                     return
                 except _lib.JitterRetry as r:
-                    used = r.mask
+                    used = self._jitter_used = r.mask
                     self._ck(self.lib.gp_global_step_jitter(self.h, r.mask), 'gp_global_step')
             self.global_status()                # a third failure is GP_ERR_NOT_PD -> LinAlgError
             self._jitter_hint = used
@@ -241,7 +242,9 @@ class ShardEngine(object):
                 break
             except _lib.JitterRetry as r:
                 jitter = r.mask
-        self.last_jitter = jitter               # 0, or the mask of the matrices that needed the reference's 1e-7 jitter in this evaluation
+        # 0, or the mask of the matrices that needed the reference's 1e-7 jitter in this evaluation (found by finish(), or -- after an evaluation that needed
+        # it -- already inside global_step())
+        self.last_jitter = jitter | self._jitter_used
         if want_embedding_grads:
             out['grad_X_mu'] = self.download('GRAD_X_MU')
             if not self.regime_A_hint:
@@ -249,6 +252,7 @@ class ShardEngine(object):
         return out
 
     regime_A_hint = False
+    _jitter_used = 0
     _jitter_hint = 0          # the jitter mask the previous evaluation ended up with (global_step)
 
     def set_local_statistics(self, sum_YYT, Psi2, C, sum_exp_K_ii, KL):

@@ -35,7 +35,7 @@ for rep in range(3):
 eng.close()
 same = all(np.array_equal(np.asarray(outs[0][k]), np.asarray(o[k])) for o in outs[1:] for k in ('grad_Z', 'grad_alpha')) and outs[0]['F'] == outs[1]['F'] == outs[2]['F']
 print('FIRST_EVAL', (N, D, M, Q, regime), 'jitter', jit, 'identical', same, 'F', [o['F'] for o in outs], flush=True)
-raise SystemExit(0 if (same and not any(jit)) else 1)
+raise SystemExit(0 if (same and len(set(jit)) == 1 and (not any(jit) or %(jitter_ok)r)) else 1)
 '''
 
 # eight panels with free and with fixed embeddings (the failing case and its neighbour), two panels (round 5's shape, tile kernel forced), four panels
@@ -48,7 +48,7 @@ def test_first_evaluation_of_a_fresh_process_is_bit_identical_to_the_next(tmp_pa
     bad = []
     for i, (shape, env) in enumerate(SHAPES):
         script = tmp_path / ('first_%d.py' % i)
-        script.write_text(CHILD % {'root': ROOT, 'shape': shape})
+        script.write_text(CHILD % {'root': ROOT, 'shape': shape, 'jitter_ok': False})
         r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **env))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('FIRST_EVAL')]
         print(line[0] if line else r.stderr[-500:])

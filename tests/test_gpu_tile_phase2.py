@@ -37,7 +37,8 @@ for (N, D, M, Q, alpha) in SHAPES:
     keys = ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S')
     errs = {k: float(np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))) for k in keys}
     if abs(out['F'] - ref['F']) > 1e-6 * abs(ref['F']) or max(errs.values()) > 1e-5:
-        # a failure here was seen ONCE in round 5 (grad_Z 1e-4 off at (9000, 3, 200, 6) inside a full-suite run; 0 of 40 repeats since, with the
+        # (round 6: the cause was a race in the blocked Cholesky's panel solve on the first evaluation of a fresh process -- profiles/r06_first_evaluation_race.txt,
+        # tests/test_gpu_first_evaluation.py; the diagnostics stay.)  A failure here was seen ONCE in round 5 (grad_Z 1e-4 off at (9000, 3, 200, 6) inside a full-suite run; 0 of 40 repeats since, with the
         # round-4 library as well: tools/stress_tile.sh): say everything that helps to place it -- the jitter branch, a repeat on the same context
         again = eng.evaluate(True)
         errs2 = {k: float(np.max(np.abs(np.asarray(again[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))) for k in keys}

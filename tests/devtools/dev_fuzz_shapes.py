@@ -1,6 +1,7 @@
 """Dev fuzz (GPU box): random small shapes in both regimes against the oracle -- looks for crashes / wrong answers at odd sizes
 (N below a tile, M = 1, M > N, Q up to 63, D up to 300).  r03: 70 shapes, 68 within 1e-5 (most 1e-12), two flagged with cond 2e14 / 9e11.  Usage: dev_fuzz_shapes.py [count] [seed]"""
 import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -46,7 +47,17 @@ for it in range(count):
             Kmm = d['sf2'] * np.exp(-0.5 * np.sum(np.asarray(d['alpha'])[None, None, :] * dz * dz, axis=2))
             cond = np.linalg.cond(Kmm + d['beta'] * ref['stats']['sum_exp_K_mi_K_im'])
             flag = '   <<<<<< %s, cond(Kmm + beta Psi2) = %.1e%s' % (max(errs, key=errs.get), cond, ' (float64 carries no digits there)' if cond > 1e11 else '')
-            if cond <= 1e11: bad += 1
+            if cond <= 1e11:
+                # (r06) the float64 oracle is not the truth at such conditioning: arbitrate with the long-double bound (dev_case_truth.py) where the case is small.
+                # Two cases of seeds 606 / 607 "failed" with the ORACLE 0.63 / 2.6e-3 off the truth and the library 1.2e-4 / 1.6e-5 (profiles/r06_fuzz_shapes.txt).
+                if max(errs, key=errs.get) == 'grad_Z' and N * M * M <= 2e6 and M * Q <= 500:
+                    from dev_case_truth import grad_Z_truth
+                    _, g = grad_Z_truth(d)
+                    e_lib, e_ora = (float(np.max(np.abs(np.asarray(x) - g)) / np.max(np.abs(g))) for x in (out['grad_Z'], ref['grad_Z']))
+                    flag += '  | against the long-double truth: library %.1e, oracle %.1e' % (e_lib, e_ora)
+                    if e_lib > max(1e-5, e_ora): bad += 1
+                else:
+                    bad += 1
         print((N, D, M, Q, regime), 'worst %.1e%s' % (worst, flag), flush=True)
     except Exception as e:
         bad += 1

@@ -1,6 +1,8 @@
 // Generic FP64 GEMM on the 4x4x4 matrix-core instruction (see mma_f64.h): 128x128 tile per 256-thread
 // workgroup, 16-deep k-chunks double-buffered through LDS, two workgroups per CU.
 // Used by the global step (M x M algebra) and, through the same building blocks, by the phase kernels.
+#include <cstdio>
+#include <cstdlib>
 #include "gp_common.h"
 #include "gemm32.h"
 #include <algorithm>
@@ -122,7 +124,25 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int ti
   }
 }
 
+// Does the stored rectangle of an operand (rows x cols doubles, leading dimension ld) share an element with C (m x n, ldc)?  Same leading dimension = two
+// windows of one parent matrix: row and column ranges from the pointer difference; otherwise the address ranges decide (conservative).
+static bool operand_meets_c(const double* X, long rows, long cols, long ld, const double* C, long m, long n, long ldc) {
+  const double *x1 = X + (rows - 1) * ld + cols, *c1 = C + (m - 1) * ldc + n;
+  if (x1 <= C || c1 <= X) return false;
+  if (ld != ldc) return true;
+  const long d = C - X, dr = (d >= 0 ? d : d - (ld - 1)) / ld, dc = d - dr * ld;      // C(0,0) sits at row dr, column dc of X's frame (floor division)
+  auto hit = [&](long r0, long c0) { return r0 < rows && r0 + m > 0 && c0 < cols && c0 + n > 0; };
+  return hit(dr, dc) || hit(dr + 1, dc - ld);                                         // a window may straddle the parent's row end in X's frame
+}
+
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p) {
+  // No product here may write a tile another workgroup still reads: C must not share an element with A or B (the in-place panel solve of the blocked
+  // Cholesky did until r06 -- a race visible only on a cold start, profiles/r06_first_evaluation_race.txt).  A programming error, never a user's: abort.
+  if (operand_meets_c(p.A, la == K_CONTIG ? m : p.K, la == K_CONTIG ? p.K : m, p.lda, p.C, m, n, p.ldc) ||
+      operand_meets_c(p.B, lb == K_CONTIG ? n : p.K, lb == K_CONTIG ? p.K : n, p.ldb, p.C, m, n, p.ldc)) {
+    fprintf(stderr, "gparml: launch_gemm called with C overlapping an operand (m %d n %d k %d)\n", m, n, p.K);
+    abort();
+  }
   dim3 grid(n / TILE, m / TILE, batch * p.splits), block(256);
   if (!p.big && (long)(n / TILE) * (m / TILE) * batch <= 256) {
     // few tiles (the global step): 32 x 32 tiles spread the product over the chip; split-k is not needed there

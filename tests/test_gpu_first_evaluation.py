@@ -6,7 +6,9 @@ processes (never the second evaluation, never after another context had run in t
 unreproduced failure (tests/test_gpu_tile_phase2.py runs its evaluations in a fresh child process).  Cause: the panel solve of the blocked Cholesky, L21 = A21 L11^-T, ran IN
 PLACE through the 32 x 32-tile product -- four workgroups per 32 rows, each reading all 128 columns and overwriting 32 of them; the race was hidden by timing except on a
 cold start.  Fix: the product goes to the work panel and a copy kernel puts it in place (csrc/linalg.hip, potrf_inverse_batched; profiles/r06_first_evaluation_race.txt).
-Here: fresh child processes, one shape each, three evaluations: no jitter, and the first bit-identical to the second and third."""
+Here: fresh child processes, one shape each, three evaluations: no jitter, and the first bit-identical to the second and third.  How often the old library showed it
+depends on the box (40-70 % of the processes on one, 15-25 % on another, where four processes at the failing shape passed): sixteen processes at the two exposed shapes;
+the structural guard is launch_gemm's refusal of a product whose C shares an element with an operand (csrc/gemm.hip)."""
 import os
 import subprocess
 import sys
@@ -38,10 +40,10 @@ print('FIRST_EVAL', (N, D, M, Q, regime), 'jitter', jit, 'identical', same, 'F',
 raise SystemExit(0 if (same and len(set(jit)) == 1 and (not any(jit) or %(jitter_ok)r)) else 1)
 '''
 
-# eight panels with free and with fixed embeddings (the failing case and its neighbour), two panels (round 5's shape, tile kernel forced), four panels
-SHAPES = [((1100, 2, 1024, 8, 'B', 0.8), {}), ((1100, 2, 1024, 8, 'B', 0.8), {}), ((1100, 2, 1024, 8, 'B', 0.8), {}), ((1100, 2, 1024, 8, 'B', 0.8), {}),
-          ((1100, 2, 1024, 8, 'A', 0.8), {}), ((9000, 3, 200, 6, 'B', 0.3), {'GPARML_B_PHASE2': 'tiles'}), ((9000, 3, 200, 6, 'B', 0.3), {'GPARML_B_PHASE2': 'tiles'}),
-          ((4096, 100, 512, 10, 'A', 0.3), {}), ((1100, 2, 768, 8, 'B', 0.8), {})]
+# eight panels with free embeddings (the exposed shapes) and with fixed ones, two panels (round 5's shape, tile kernel forced), four and six panels
+SHAPES = ([((1100, 2, 1024, 8, 'B', 0.8), {})] * 12 + [((1100, 2, 1024, 10, 'B', 0.8), {})] * 4 +
+          [((1100, 2, 1024, 8, 'A', 0.8), {}), ((9000, 3, 200, 6, 'B', 0.3), {'GPARML_B_PHASE2': 'tiles'}), ((9000, 3, 200, 6, 'B', 0.3), {'GPARML_B_PHASE2': 'tiles'}),
+           ((4096, 100, 512, 10, 'A', 0.3), {}), ((1100, 2, 768, 8, 'B', 0.8), {})])
 
 
 def test_first_evaluation_of_a_fresh_process_is_bit_identical_to_the_next(tmp_path):

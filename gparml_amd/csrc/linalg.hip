@@ -74,8 +74,8 @@ int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* 
       // each reading all 128 columns of the rows and overwriting 32 of them: a race that timing hid -- every workgroup resident and in step, the reads over long
       // before the first store -- except on a cold start: the FIRST evaluation of a fresh process at M = 1024 with free embeddings came back with both
       // factorisations flagged in 40-70 % of the processes (NaN from panel 1 on; the evaluator then repeats the step with the reference's 1e-7 jitter: F 2.9e-8,
-      // grad_Z 4.1e-6 off -- inside the parity tolerance on a well-conditioned problem, 1e-4 on a badly conditioned one: in all likelihood round 5's
-      // unreproduced test_gpu_tile_phase2 failure, whose evaluations run in a fresh child process).  The product goes to the work panel and a copy kernel puts it
+      // grad_Z 4.1e-6 off -- inside the parity tolerance on a well-conditioned problem; on round 5's failing test_gpu_tile_phase2 shape 9.973e-5, the
+      // logged 9.97e-5: that was this, its evaluations run in a fresh child process).  The product goes to the work panel and a copy kernel puts it
       // in place (+ ~5 us per panel; the 128 x 128-tile kernel in place -- one workgroup owns all columns of its rows -- is safe too but costs 20 us per panel).
       // profiles/r06_first_evaluation_race.txt, tests/test_gpu_first_evaluation.py.
       p.C = Twork; p.ldc = NB; p.sC = (long)rem * NB * NB;

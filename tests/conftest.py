@@ -13,6 +13,35 @@ GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'jitter_expected: the test drives the reference\'s 1e-7 jitter branch on purpose (partial_terms.py:452-456)')
+
+
+@pytest.fixture(autouse=True)
+def _no_silent_jitter(request):
+    """A GPU test that takes the reference's jitter branch without saying so fails (round 6).  The branch is silent by design -- a failed factorisation is repeated with
+    1e-7 on the diagonal and the evaluation goes on -- and that is how a WRONG factorisation hides: round 5's one unreproduced failure was a spurious failure flag from a
+    race in the blocked Cholesky, then a correct evaluation of the jittered problem, 9.97e-5 off in grad_Z and inside the tolerance everywhere else
+    (profiles/r06_first_evaluation_race.txt).  Every retry goes through gp_global_step_jitter(h, mask != 0), whatever the host surface: counted here, in-process."""
+    if 'gpu' not in request.keywords:
+        yield
+        return
+    from gparml_amd import _lib
+    lib = _lib.load()
+    orig = lib.gp_global_step_jitter
+    masks = []
+
+    def counted(h, mask):
+        if mask:
+            masks.append(int(mask))
+        return orig(h, mask)
+    lib.gp_global_step_jitter = counted
+    try:
+        yield
+    finally:
+        lib.gp_global_step_jitter = orig
+    if masks and request.node.get_closest_marker('jitter_expected') is None:
+        pytest.fail('the 1e-7 jitter retry was taken %d time(s) (masks %s) in a test that is not marked jitter_expected: a factorisation failed where none should'
+                    % (len(masks), sorted(set(masks))))
 
 
 # Order of the GPU suite under `-x` (round-4 review, "What's weak" 2): the golden / oracle parity files first -- they carry the

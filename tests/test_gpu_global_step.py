@@ -25,6 +25,7 @@ def _indefinite_stats(d, shift):
     return dict(sum_YYT=float(np.sum(d['Y'] ** 2)), Psi2=Psi2, C=C, Psi0=d['sf2'] * d['Y'].shape[0], KL=0.0), Kmm
 
 
+@pytest.mark.jitter_expected
 def test_jitter_retry_matches_the_reference_branch():
     """A barely indefinite Kmm + beta*Psi2 (smallest eigenvalue -5e-8): the reference adds 1e-7*I and carries on
     (partial_terms.py:454-456); the device path reports GP_RETRY_JITTER once and repeats the global step with the jitter."""
@@ -65,6 +66,7 @@ def _relmax(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(np.asarray(b))), 1e-300))
 
 
+@pytest.mark.jitter_expected
 def test_jitter_branch_gradients_against_the_restated_reference_branch():
     """What the jitter branch does to the GRADIENTS.  The reference adds 1e-7*I only inside logmarglik (log-determinant and the trace
     term, partial_terms.py:452-461); dF_dKmm / dF_dexp_K_miY / dF_dexp_K_mi_K_im / grad_beta keep Kmm_plus_op_inv = inv(Kmm + beta Psi2)
@@ -133,6 +135,7 @@ def test_coincident_and_nearly_coincident_inducing_points():
         assert v <= 2e-4, (k, v)
 
 
+@pytest.mark.jitter_expected
 def test_jitter_that_does_not_help_is_a_linalg_error():
     """Smallest eigenvalue -1e-6: still indefinite with 1e-7*I -> the reference's assertion (partial_terms.py:459-461) -> LinAlgError."""
     from gparml_amd.engine import ShardEngine
@@ -151,6 +154,7 @@ def test_jitter_that_does_not_help_is_a_linalg_error():
     eng.close()
 
 
+@pytest.mark.jitter_expected
 def test_evaluate_recovers_through_the_retry():
     """ShardEngine.evaluate / DistributedEvaluator.evaluate repeat global step + phase 2 when finish() asks for the jitter."""
     from gparml_amd.dist import DistributedEvaluator

@@ -37,6 +37,7 @@ for (N, D, M, Q, regime, alpha, emb) in SHAPES:
     for rep in range(3):                              # the second and third evaluation start from buffers the first one filled: refilled with NaN in between
         eng.set_globals(d['Z'], d['sf2'], d['alpha'], d['beta'])
         outs.append(eng.evaluate(emb))
+        assert eng.last_jitter == 0, ((N, D, M, Q, regime), 'jitter retry', eng.last_jitter)      # none of these shapes needs it (conftest._no_silent_jitter)
     eng.close()
     # (fixed variances: the reference's grad_X_S divides by S = 0, partial_terms.py:400-431 -- not compared, as in tests/test_gpu_parity.py)
     keys = ['grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta'] + (['grad_X_mu'] if emb else []) + (['grad_X_S'] if emb and regime == 'B' else [])

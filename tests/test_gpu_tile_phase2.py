@@ -36,13 +36,14 @@ for (N, D, M, Q, alpha) in SHAPES:
     out = eng.evaluate(True)
     keys = ('grad_Z', 'grad_alpha', 'grad_sf2', 'grad_beta', 'grad_X_mu', 'grad_X_S')
     errs = {k: float(np.max(np.abs(np.asarray(out[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))) for k in keys}
-    if abs(out['F'] - ref['F']) > 1e-6 * abs(ref['F']) or max(errs.values()) > 1e-5:
+    jit = eng.last_jitter      # none of these shapes needs the reference's jitter: a retry here is a factorisation that failed where it should not (conftest._no_silent_jitter)
+    if jit or abs(out['F'] - ref['F']) > 1e-6 * abs(ref['F']) or max(errs.values()) > 1e-5:
         # (round 6: the cause was a race in the blocked Cholesky's panel solve on the first evaluation of a fresh process -- profiles/r06_first_evaluation_race.txt,
         # tests/test_gpu_first_evaluation.py; the diagnostics stay.)  A failure here was seen ONCE in round 5 (grad_Z 1e-4 off at (9000, 3, 200, 6) inside a full-suite run; 0 of 40 repeats since, with the
         # round-4 library as well: tools/stress_tile.sh): say everything that helps to place it -- the jitter branch, a repeat on the same context
         again = eng.evaluate(True)
         errs2 = {k: float(np.max(np.abs(np.asarray(again[k]) - np.asarray(ref[k]))) / np.max(np.abs(ref[k]))) for k in keys}
-        print('TILE_FAIL', (N, D, M, Q), 'F', out['F'], ref['F'], 'errors', errs, 'jitter mask', eng.last_jitter, '| repeated on the same context:', errs2,
+        print('TILE_FAIL', (N, D, M, Q), 'F', out['F'], ref['F'], 'errors', errs, 'jitter mask', jit, '| repeated on the same context:', errs2,
               'jitter mask', eng.last_jitter, flush=True)
         raise SystemExit(1)
     eng.close()

@@ -71,6 +71,7 @@ SIGNATURES = {
     'gp_debug_potrf_inverse': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
     'gp_debug_gemm_bench': (ctypes.c_int, [ctypes.c_int] * 7 + [_dp]),
     'gp_debug_peek': (ctypes.c_int, [_vp, ctypes.c_char_p, _dp, ctypes.c_long]),
+    'gp_debug_operands_overlap': (ctypes.c_int, [ctypes.c_long] * 8),
 }
 
 _lib = None

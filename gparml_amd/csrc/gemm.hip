@@ -1,6 +1,7 @@
 // Generic FP64 GEMM on the 4x4x4 matrix-core instruction (see mma_f64.h): 128x128 tile per 256-thread
 // workgroup, 16-deep k-chunks double-buffered through LDS, two workgroups per CU.
 // Used by the global step (M x M algebra) and, through the same building blocks, by the phase kernels.
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include "gp_common.h"
@@ -124,15 +125,18 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(GemmP p, int ti
   }
 }
 
-// Does the stored rectangle of an operand (rows x cols doubles, leading dimension ld) share an element with C (m x n, ldc)?  Same leading dimension = two
-// windows of one parent matrix: row and column ranges from the pointer difference; otherwise the address ranges decide (conservative).
-static bool operand_meets_c(const double* X, long rows, long cols, long ld, const double* C, long m, long n, long ldc) {
-  const double *x1 = X + (rows - 1) * ld + cols, *c1 = C + (m - 1) * ldc + n;
-  if (x1 <= C || c1 <= X) return false;
+// Does the stored rectangle of an operand (rows x cols doubles, leading dimension ld, first element at element address x0) share an element with C (m x n, ldc, at c0)?
+// Same leading dimension = two windows of one parent matrix: row and column ranges from the address difference; otherwise the address ranges decide (conservative).
+bool windows_meet(long x0, long rows, long cols, long ld, long c0, long m, long n, long ldc) {
+  const long x1 = x0 + (rows - 1) * ld + cols, c1 = c0 + (m - 1) * ldc + n;
+  if (x1 <= c0 || c1 <= x0) return false;
   if (ld != ldc) return true;
-  const long d = C - X, dr = (d >= 0 ? d : d - (ld - 1)) / ld, dc = d - dr * ld;      // C(0,0) sits at row dr, column dc of X's frame (floor division)
-  auto hit = [&](long r0, long c0) { return r0 < rows && r0 + m > 0 && c0 < cols && c0 + n > 0; };
-  return hit(dr, dc) || hit(dr + 1, dc - ld);                                         // a window may straddle the parent's row end in X's frame
+  const long d = c0 - x0, dr = (d >= 0 ? d : d - (ld - 1)) / ld, dc = d - dr * ld;   // C(0,0) sits at row dr, column dc of X's frame (floor division)
+  auto hit = [&](long r0, long k0) { return r0 < rows && r0 + m > 0 && k0 < cols && k0 + n > 0; };
+  return hit(dr, dc) || hit(dr + 1, dc - ld);                                        // the same place one row further down, ld columns to the left
+}
+static bool operand_meets_c(const double* X, long rows, long cols, long ld, const double* C, long m, long n, long ldc) {
+  return windows_meet((long)(reinterpret_cast<uintptr_t>(X) / sizeof(double)), rows, cols, ld, (long)(reinterpret_cast<uintptr_t>(C) / sizeof(double)), m, n, ldc);
 }
 
 void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, const GemmP& p) {
@@ -164,6 +168,10 @@ void launch_gemm(hipStream_t st, Layout la, Layout lb, int m, int n, int batch, 
 }  // namespace gp
 
 // ---- test hook -------------------------------------------------------------------------------------------------
+extern "C" int gp_debug_operands_overlap(long x_off, long rows, long cols, long ld, long c_off, long m, long n, long ldc) {
+  return gp::windows_meet(x_off, rows, cols, ld, c_off, m, n, ldc) ? 1 : 0;
+}
+
 extern "C" int gp_debug_gemm(int device, int ta, int tb, int m, int n, int k, double alpha, const double* A, const double* B,
                              double beta, double* C) {
   using namespace gp;

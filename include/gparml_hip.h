@@ -237,6 +237,10 @@ int gp_debug_gemm_bench(int device, int ta, int tb, int m, int n, int k, int ite
 /* raw copy of one of the global step's internal buffers ("Linv", "Inv", "E", "PsiE", "T1", "T2", "dFdK", "Bbar", "Abar", "Bm", "gK", "gs") after a
  * stream synchronisation; n = capacity of out in doubles (tests/devtools/dev_tail_diff.py) */
 int gp_debug_peek(gp_ctx* ctx, const char* name, double* out, long n);
+/* the rule the internal matrix products are launched under (csrc/gemm.hip, launch_gemm aborts when it fails: the blocked Cholesky's in-place panel solve raced until
+ * round 6): does an operand stored as rows x cols doubles with leading dimension ld, starting at element offset x_off of a buffer, share an element with the result
+ * m x n, leading dimension ldc, at offset c_off of the SAME buffer?  Host arithmetic only (no device needed); returns 0 or 1. */
+int gp_debug_operands_overlap(long x_off, long rows, long cols, long ld, long c_off, long m, long n, long ldc);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 #include "mma_f64.h"
 #include "fexp.h"
 #include "quad_mma.h"
+#include "lane_reduce.h"
 #include <algorithm>
 
 namespace gp {
@@ -419,18 +420,45 @@ __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Arg
     const int lane = lane_id(), mc = mc0 + lane;
     const double* wn = WP + n * QT;                      // wave-uniform
     const double* mun = MUP + n * QT;
-    double s0 = r;
+    // The wave's 3 QT + 1 sums.  QT <= 10 (r06): two reduce-scatters of half the latent dimensions each (lane_reduce.h) -- about one cross-lane move and add per value
+    // where the butterfly sums take six, one LDS store by the lanes that own a sum -- and no scratch left in psi2_cols_kernel<10, true>: phase 2 at M = 128, Q = 10
+    // 2.75 -> 2.56 ms per 1e5 points, M = 1024 neutral.  QT >= 12 keeps the butterflies: same box, M = 512, the reduce-scatter form measured 42.3 -> 42.6 (Q = 14) and
+    // 47.3 -> 50.7 ms (Q = 16) -- its 3 QT / 2 values next to t[] change the allocation of the row loop (profiles/r06_gplvm_experiments.txt item 15).
+    if constexpr (QT <= 10) {
+    static_for<0, 2>([&](auto cc) {
+      constexpr int QC = QT / 2, q0 = decltype(cc)::value * QC;
+      constexpr bool first = q0 == 0;
+      constexpr int NV = 3 * QC + (first ? 1 : 0), O = first ? 1 : 0;
+      double v[NV];
+      if (first) v[0] = r;
 #pragma unroll
-    for (int q = 0; q < QT; ++q) {
-      const double zq = KEEP ? z[q] : ZP[(long)mc * QT + q];
-      const double gq = -alphaP[q] * (zq * r - t[q]) + wn[q] * (2.0 * mun[q] * r - zq * r - t[q]);
-      if (KEEP) g[q] += gq;
-      else if (active && mc < a.M && q < a.Q) { double* dst = G + (long)mc * a.Q + q; *dst = ((n == n0) ? 0.0 : *dst) + gq; }
-      const double s1 = wave_sum(zq * r), s2 = wave_sum(zq * zq * r), s3 = wave_sum(zq * t[q]);
-      if (lane == 0) { red[wave][1 + q] = s1; red[wave][1 + QT + q] = s2; red[wave][1 + 2 * QT + q] = s3; }
+      for (int qi = 0; qi < QC; ++qi) {
+        const int q = q0 + qi;
+        const double zq = KEEP ? z[KEEP ? q : 0] : ZP[(long)mc * QT + q];
+        const double gq = -alphaP[q] * (zq * r - t[q]) + wn[q] * (2.0 * mun[q] * r - zq * r - t[q]);
+        if (KEEP) g[KEEP ? q : 0] += gq;
+        else if (active && mc < a.M && q < a.Q) { double* dst = G + (long)mc * a.Q + q; *dst = ((n == n0) ? 0.0 : *dst) + gq; }
+        v[O + qi] = zq * r; v[O + QC + qi] = zq * zq * r; v[O + 2 * QC + qi] = zq * t[q];
+      }
+      const double tot = wave_reduce_scatter<NV>(v, lane);
+      const int j = lane - O, kq = (j >= 2 * QC) ? 2 : (j >= QC ? 1 : 0);
+      const int row = (first && lane == 0) ? 0 : 1 + kq * QT + q0 + (j - kq * QC);
+      if (lane < NV) red[wave][row] = tot;
+    });
+    } else {
+      double s0 = r;
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        const double zq = KEEP ? z[KEEP ? q : 0] : ZP[(long)mc * QT + q];
+        const double gq = -alphaP[q] * (zq * r - t[q]) + wn[q] * (2.0 * mun[q] * r - zq * r - t[q]);
+        if (KEEP) g[KEEP ? q : 0] += gq;
+        else if (active && mc < a.M && q < a.Q) { double* dst = G + (long)mc * a.Q + q; *dst = ((n == n0) ? 0.0 : *dst) + gq; }
+        const double s1 = wave_sum(zq * r), s2 = wave_sum(zq * zq * r), s3 = wave_sum(zq * t[q]);
+        if (lane == 0) { red[wave][1 + q] = s1; red[wave][1 + QT + q] = s2; red[wave][1 + 2 * QT + q] = s3; }
+      }
+      s0 = wave_sum(s0);
+      if (lane == 0) red[wave][0] = s0;
     }
-    s0 = wave_sum(s0);
-    if (lane == 0) red[wave][0] = s0;
     __syncthreads();
     for (int i = 64 * wave + lane; i < PW; i += blockDim.x) {
       double sum = red[0][i];
@@ -602,18 +630,19 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
           s1[qi] = fma(zq, r, s1[qi]); s2[qi] = fma(zq * zq, r, s2[qi]); s3[qi] = fma(zq, tq, s3[qi]);
         }
       }
-      // the waves' sums go to pp as they are, one group per wave (a.ngrp = waves): psi2_points_finish_kernel adds the groups in wave order -- the order the
-      // LDS hand-over of r03-r05 used, so the bits are the same -- and the [waves][PW] LDS array with its second barrier is gone (r06)
-      if (first) {
-        s0 = wave_sum(s0);
-        if (lane == 0) ppw[0] = s0;
-      }
+      // the waves' sums go to pp as they are, one group per wave (a.ngrp = waves): psi2_points_finish_kernel adds the groups in wave order, and the [waves][PW]
+      // LDS array of r03-r05 with its second barrier is gone (r06).  The sums across the wave as ONE reduce-scatter of the pass's 3 QC (+ 1) values (lane_reduce.h):
+      // about one cross-lane move and one add per value where 3 QC + 1 butterfly sums took six of each (372 ds_bpermute per point at QT = 10), and one store
+      // by the lanes that end up owning a sum instead of 3 QC + 1 single-lane stores.
+      constexpr int NV = 3 * QC + (first ? 1 : 0);
+      double v[NV];
+      if (first) v[0] = s0;
 #pragma unroll
-      for (int qi = 0; qi < QC; ++qi) {
-        const int q = q0 + qi;
-        const double x1 = wave_sum(s1[qi]), x2 = wave_sum(s2[qi]), x3 = wave_sum(s3[qi]);
-        if (lane == 0) { ppw[(long)(1 + q) * a.Np] = x1; ppw[(long)(1 + QT + q) * a.Np] = x2; ppw[(long)(1 + 2 * QT + q) * a.Np] = x3; }
-      }
+      for (int qi = 0; qi < QC; ++qi) { v[(first ? 1 : 0) + qi] = s1[qi]; v[(first ? 1 : 0) + QC + qi] = s2[qi]; v[(first ? 1 : 0) + 2 * QC + qi] = s3[qi]; }
+      const double tot = wave_reduce_scatter<NV>(v, lane);
+      const int j = lane - (first ? 1 : 0), kq = (j >= 2 * QC) ? 2 : (j >= QC ? 1 : 0);
+      const int row = (first && lane == 0) ? 0 : 1 + kq * QT + q0 + (j - kq * QC);
+      if (lane < NV) ppw[(long)row * a.Np] = tot;
     });
     __syncthreads();       // every row of rt has been read and cleared before the next point's tiles add to it
   }

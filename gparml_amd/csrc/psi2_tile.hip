@@ -20,6 +20,7 @@
 #include "gp_common.h"
 #include "fexp.h"
 #include "quad_mma.h"
+#include "lane_reduce.h"
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -36,38 +37,6 @@ struct PT2Args {
   long long* dbg;       // timing build (GPARML_TILE_TIMING): [blocks][8 waves][8 sections] cycle totals
 };
 
-template <int MASK>
-__device__ __forceinline__ double lane_xor(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  if constexpr (MASK == 32) {
-    lo = __shfl_xor(lo, 32); hi = __shfl_xor(hi, 32);
-  } else {
-    constexpr int pat = 0x1F | (MASK << 10);      // ds_swizzle bit mode: and 0x1f, or 0, xor MASK (inside 32 lanes; no memory access)
-    lo = __builtin_amdgcn_ds_swizzle(lo, pat); hi = __builtin_amdgcn_ds_swizzle(hi, pat);
-  }
-  return __hiloint2double(hi, lo);
-}
-// one reduce-scatter stage over lane bit BIT: the lane pair (l, l ^ 2^BIT) splits the N values, lane bit 0 keeps the even indices
-template <int N, int BIT>
-__device__ __forceinline__ void halve(const double (&v)[N], double (&w)[(N + 1) / 2], int lane) {
-  const bool sel = (lane >> BIT) & 1;
-#pragma unroll
-  for (int i = 0; i < N / 2; ++i) {
-    const double keep = sel ? v[2 * i + 1] : v[2 * i];
-    const double give = sel ? v[2 * i] : v[2 * i + 1];     // selected BEFORE the cross-lane move: every lane executes the move
-    w[i] = keep + lane_xor<(1 << BIT)>(give);
-  }
-  if constexpr (N & 1) w[N / 2] = v[N - 1] + lane_xor<(1 << BIT)>(v[N - 1]);
-}
-// sum over the 16 lanes that differ in lane bits 2..5; lane l returns the complete sum of v[l >> 2] (if l >> 2 < N), N <= 16
-template <int N>
-__device__ __forceinline__ double reduce16(const double (&v)[N], int lane) {
-  constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
-  static_assert((N3 + 1) / 2 == 1, "reduce16 handles up to 16 values");
-  double a[N1], b[N2], c[N3], d[1];
-  halve<N, 2>(v, a, lane); halve<N1, 3>(a, b, lane); halve<N2, 4>(b, c, lane); halve<N3, 5>(c, d, lane);
-  return d[0];
-}
 __device__ __forceinline__ double mul_asm(double a, double b) {   // ordered with the asm MFMAs around it (the compiler may not move it)
   double r;
   asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

@@ -350,10 +350,6 @@ struct PB2Args {
   long N, Np; int M, Mp, Q, QB, nslab, ppb, ngrp;   // nslab = ceil(M/64) column slabs in ngrp groups of <= 4; ppb points per workgroup
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 // the lane's index inside its wave from the execution mask (v_mbcnt): no register has to carry threadIdx.x through a kernel's hot loop for the few places
 // behind it that need the lane (psi2_cols_kernel<10, true> spilled it: the library's last scratch allocation, r06)
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -420,13 +416,14 @@ __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Arg
     const int lane = lane_id(), mc = mc0 + lane;
     const double* wn = WP + n * QT;                      // wave-uniform
     const double* mun = MUP + n * QT;
-    // The wave's 3 QT + 1 sums.  QT <= 10 (r06): two reduce-scatters of half the latent dimensions each (lane_reduce.h) -- about one cross-lane move and add per value
-    // where the butterfly sums take six, one LDS store by the lanes that own a sum -- and no scratch left in psi2_cols_kernel<10, true>: phase 2 at M = 128, Q = 10
-    // 2.75 -> 2.56 ms per 1e5 points, M = 1024 neutral.  QT >= 12 keeps the butterflies: same box, M = 512, the reduce-scatter form measured 42.3 -> 42.6 (Q = 14) and
-    // 47.3 -> 50.7 ms (Q = 16) -- its 3 QT / 2 values next to t[] change the allocation of the row loop (profiles/r06_gplvm_experiments.txt item 15).
-    if constexpr (QT <= 10) {
-    static_for<0, 2>([&](auto cc) {
-      constexpr int QC = QT / 2, q0 = decltype(cc)::value * QC;
+    // The wave's 3 QT + 1 sums as reduce-scatters (lane_reduce.h, r06): about one cross-lane move and one add per value where butterfly sums take six of each, and
+    // one LDS store by the lanes that own a sum.  QT <= 10: two passes of half the latent dimensions (phase 2 at M = 128, Q = 10: 2.75 -> 2.56 ms per 1e5 points,
+    // M = 1024 neutral).  QT >= 12: passes of TWO dimensions -- with QT / 2 per pass the values next to t[] changed the allocation of the row loop (M = 512, Q = 16:
+    // 47.3 -> 50.7 ms); with two: Q = 16 47.85 -> 47.3, Q = 14 42.5 -> 42.9, Q = 13 unchanged, M = 128 / Q = 14 3.80 -> 3.68.  Either way no instantiation of this
+    // kernel has a scratch allocation any more (<10, true> 16 B, <12 / 14, false> 20 / 28 B before).  profiles/r06_gplvm_experiments.txt item 15.
+    constexpr int QC = QT <= 10 ? QT / 2 : 2;
+    static_for<0, QT / QC>([&](auto cc) {
+      constexpr int q0 = decltype(cc)::value * QC;
       constexpr bool first = q0 == 0;
       constexpr int NV = 3 * QC + (first ? 1 : 0), O = first ? 1 : 0;
       double v[NV];
@@ -445,20 +442,6 @@ __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Arg
       const int row = (first && lane == 0) ? 0 : 1 + kq * QT + q0 + (j - kq * QC);
       if (lane < NV) red[wave][row] = tot;
     });
-    } else {
-      double s0 = r;
-#pragma unroll
-      for (int q = 0; q < QT; ++q) {
-        const double zq = KEEP ? z[KEEP ? q : 0] : ZP[(long)mc * QT + q];
-        const double gq = -alphaP[q] * (zq * r - t[q]) + wn[q] * (2.0 * mun[q] * r - zq * r - t[q]);
-        if (KEEP) g[KEEP ? q : 0] += gq;
-        else if (active && mc < a.M && q < a.Q) { double* dst = G + (long)mc * a.Q + q; *dst = ((n == n0) ? 0.0 : *dst) + gq; }
-        const double s1 = wave_sum(zq * r), s2 = wave_sum(zq * zq * r), s3 = wave_sum(zq * t[q]);
-        if (lane == 0) { red[wave][1 + q] = s1; red[wave][1 + QT + q] = s2; red[wave][1 + 2 * QT + q] = s3; }
-      }
-      s0 = wave_sum(s0);
-      if (lane == 0) red[wave][0] = s0;
-    }
     __syncthreads();
     for (int i = 64 * wave + lane; i < PW; i += blockDim.x) {
       double sum = red[0][i];

@@ -9,7 +9,7 @@
 namespace gp {
 
 // psi2 of every point: out[n][j][m]   (partial_terms.py:45-48, kernel_exp.py:143-146)
-__global__ void __launch_bounds__(256) psi2_points_kernel(const double* __restrict__ Kaug, long ld, const double* __restrict__ LE, int Mp,
+__global__ void __launch_bounds__(256) psi2_points_kernel(const double* __restrict__ Kaug, long ld, const double* __restrict__ LE, int Mp, bool le_il,
                                                            const double* __restrict__ Vn, const double* __restrict__ DZ2, long N, int M, int Q,
                                                            int regimeA, double* __restrict__ out) {
   const long total = N * (long)M * M;
@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) psi2_points_kernel(const double* __restri
     if (regimeA) {
       v = Kaug[n * ld + m1] * Kaug[n * ld + m2];
     } else {
-      double e = LE[n * Mp + m1] + LE[n * Mp + m2];
+      double e = LE[le_index(le_il, n, m1, Mp)] + LE[le_index(le_il, n, m2, Mp)];      // (the layout of LE: csrc/psi2.hip)
       for (int q = 0; q < Q; ++q) e = fma(Vn[n * Q + q], DZ2[((long)m1 * M + m2) * Q + q], e);
       v = exp(e);
     }
@@ -141,7 +141,7 @@ int compat_build(gp_ctx* c, int which, double** out, long* count) {
   if (needs_p2) {
     if (which == GP_ARR_PSI2_POINTS) p2 = buf; else GP_TRY_RC(dalloc_bytes(c, (void**)&p2, (size_t)(N * M * M) * 8, DA_RAW));
     if (!c->regime_A) { const int rc = run_dz2(c); if (rc != GP_OK) return rc; }
-    hipLaunchKernelGGL(psi2_points_kernel, dim3(grid_for(N * M * M)), dim3(256), 0, c->stream, c->Kaug, (long)c->LDK, c->LE, c->Mp, c->Vn, c->DZ2,
+    hipLaunchKernelGGL(psi2_points_kernel, dim3(grid_for(N * M * M)), dim3(256), 0, c->stream, c->Kaug, (long)c->LDK, c->LE, c->Mp, !b_generic(c) && le_interleaved(c->QB), c->Vn, c->DZ2,
                        N, (int)M, (int)Q, c->regime_A ? 1 : 0, p2);
   }
   switch (which) {

@@ -282,6 +282,10 @@ int check_global_from(gp_ctx* c, const double* h);
 int potrf_inverse_batched(gp_ctx* c, hipStream_t st, int Mp, int batch, double* A /*in: SPD, out: L*/, double* Linv, double* Inv,
                           double* Twork /*batch * Mp * Mp / 2 doubles*/, double* logdet2 /*device, [batch]*/, double* fail_flag /*device, [batch]*/,
                           double* splitk_ws /*may be NULL*/, size_t splitk_cap = 0);
+// layout of the free-embedding LE table (csrc/psi2.hip, b_le_kernel): four points interleaved up to the 16-wide latent tables, point-major beyond
+__host__ __device__ constexpr bool le_interleaved(int QT) { return QT <= 16; }
+__host__ __device__ inline long le_index(bool il, long n, long m, long Mp) { return il ? ((((n >> 2) * Mp + m) << 2) + (n & 3)) : n * Mp + m; }
+
 }  // namespace gp
 
 // event i of the context's timing set, if the timing level asks for it (levels: gp_ctx::timing)

@@ -43,6 +43,12 @@ __global__ void __launch_bounds__(256) b_tables_kernel(const double* __restrict_
 // writes whole rows (HBM-write bound: 16 B per (n, m)).
 //   LE  = 1/2 ln c2_n - 1/2 sum_q w_nq (mu_nq - z_mq)^2
 //   LEA = LE + sum_q V_nq z_mq^2: with it the pair exponent is LEA_nm + LEA_nm' - 2 sum_q V_nq z_mq z_m'q
+// Layout of LE (r06).  Up to the 16-wide latent tables psi2_pairs_kernel is its only reader in the hot path, four points per trip: element (n, m) sits at
+// ((n / 4) Mp + m) 4 + n % 4, so a lane reads the four values of its row m (and of its column m') with two 16-byte loads instead of four 8-byte ones.  The kernel
+// was bound by the NUMBER of its vector-memory instructions as much as by the FP64 pipe (the texture addresser takes 16 cycles per wave-instruction whatever
+// the width: a timing build with one of the two 8-byte loads per point dropped ran 10 % faster at Q = 10, 20 % at Q = 5; profiles/r06_gplvm_experiments.txt item 16).
+// Wider tables (the matrix-core pair kernel reads LEA) keep LE point-major for the compat path.
+
 template <int QT, int CPL>
 __global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ MUP, const double* __restrict__ WP, const double* __restrict__ V2P,
                                                     const double* __restrict__ lnc2h, const double* __restrict__ ZP, long N, int M, int Mp,
@@ -57,6 +63,8 @@ __global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ MU
 #pragma unroll
     for (int q = 0; q < QT; ++q) z[c][q] = ZP[(long)(col + c) * QT + q];
   const long row0 = blockIdx.y * 16L;
+  constexpr bool IL = le_interleaved(QT);
+  double e4[IL ? 4 : 1][CPL];
 #pragma unroll 2
   for (int r = 0; r < 16; ++r) {
     const long n = row0 + r;                    // < Np (a multiple of 128)
@@ -79,13 +87,32 @@ __global__ void __launch_bounds__(256) b_le_kernel(const double* __restrict__ MU
       ea[c] = live ? e[c] - 0.5 * t : kPadLog;   // V = -V2P / 2
     }
     if (CPL == 2) {
-      double2 a, b2;
-      a.x = e[0]; a.y = e[CPL - 1]; b2.x = ea[0]; b2.y = ea[CPL - 1];
-      *reinterpret_cast<double2*>(&LE[n * Mp + col]) = a;
+      double2 b2;
+      b2.x = ea[0]; b2.y = ea[CPL - 1];
       *reinterpret_cast<double2*>(&LEA[n * Mp + col]) = b2;
     } else {
-      LE[n * Mp + col] = e[0];
       LEA[n * Mp + col] = ea[0];
+    }
+    if (IL) {
+      // four points of one column side by side (le_index): psi2_pairs_kernel reads a trip's four values with two 16-byte loads per side
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) e4[IL ? (r & 3) : 0][c] = e[c];
+      if ((r & 3) == 3) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          double* dst = LE + (((n >> 2) * Mp + col + c) << 2);
+          double2 lo2, hi2;
+          lo2.x = e4[0][c]; lo2.y = e4[IL ? 1 : 0][c]; hi2.x = e4[IL ? 2 : 0][c]; hi2.y = e4[IL ? 3 : 0][c];
+          *reinterpret_cast<double2*>(dst) = lo2;
+          *reinterpret_cast<double2*>(dst + 2) = hi2;
+        }
+      }
+    } else if (CPL == 2) {
+      double2 a;
+      a.x = e[0]; a.y = e[CPL - 1];
+      *reinterpret_cast<double2*>(&LE[n * Mp + col]) = a;
+    } else {
+      LE[n * Mp + col] = e[0];
     }
   }
 }
@@ -141,25 +168,25 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
     const double d = ZP[(long)m1 * QT + q] - ZP[(long)m2 * QT + q];
     dz[q] = -0.5 * d * d;
   }
-  const long per = (N + S - 1) / S;
+  const long per = ((N + S - 1) / S + 3) / 4 * 4;       // slices start at multiples of four points (the layout of LE)
   const long n0 = slice * per, n1 = min(N, n0 + per);
   const ExpTab xt = exp_tab_lane();
-  unsigned o1 = 8u * (unsigned)m1, o2 = 8u * (unsigned)m2;
+  unsigned o1 = 32u * (unsigned)m1, o2 = 32u * (unsigned)m2;
   double acc0 = 0.0, acc1 = 0.0;
   long n = n0;
   // (r06: the eight LE values of the NEXT trip requested at the top of the current one -- 16 more VGPRs, seven waves per SIMD instead of eight -- measured slower:
   // 13.7 -> 14.3 ms per 1e5 points at Q = 10, 15.6 -> 23.1 at Q = 16: eight waves already hide that latency; profiles/r06_gplvm_experiments.txt)
   for (; n + 4 <= n1; n += 4) {
     double e[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      // wave-uniform row base + 32-bit BYTE offsets of the lane: scalar-base addressing (global_load v, voff, s[base]), no per-lane 64-bit
-      // address arithmetic (two v_lshl_add_u64 per point before; an element index instead of a byte offset does not get it: its shift
-      // by 3 may not fit 32 bits as far as the compiler knows; the offsets pass through an empty asm, otherwise LE + offset is hoisted
-      // out of the loop as a per-lane 64-bit pointer again)
-      const char* row = reinterpret_cast<const char*>(LE + (n + u) * Mp);
+    {
+      // wave-uniform group base + 32-bit BYTE offsets of the lane: scalar-base addressing (global_load v, voff, s[base]), no per-lane 64-bit address
+      // arithmetic (the offsets pass through an empty asm, otherwise base + offset is hoisted out of the loop as a per-lane 64-bit pointer again).
+      // n is a multiple of four (the slices are): the four points' values of a column are 32 contiguous bytes (le_index)
+      const char* grp = reinterpret_cast<const char*>(LE + (n >> 2) * Mp * 4);
       asm volatile("" : "+v"(o1), "+v"(o2));
-      e[u] = *reinterpret_cast<const double*>(row + o1) + *reinterpret_cast<const double*>(row + o2);
+      const double2 a0 = *reinterpret_cast<const double2*>(grp + o1), a1 = *reinterpret_cast<const double2*>(grp + o1 + 16);
+      const double2 b0 = *reinterpret_cast<const double2*>(grp + o2), b1 = *reinterpret_cast<const double2*>(grp + o2 + 16);
+      e[0] = a0.x + b0.x; e[1] = a0.y + b0.y; e[2] = a1.x + b1.x; e[3] = a1.y + b1.y;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -176,8 +203,7 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
 #endif
   }
   for (; n < n1; ++n) {
-    const char* row = reinterpret_cast<const char*>(LE + n * Mp);
-    double e = *reinterpret_cast<const double*>(row + o1) + *reinterpret_cast<const double*>(row + o2);
+    double e = LE[le_index(true, n, m1, Mp)] + LE[le_index(true, n, m2, Mp)];
     const double* v = V2P + n * QT;
 #pragma unroll
     for (int q = 0; q < QT; ++q) e = fma(v[q], dz[q], e);

@@ -192,7 +192,7 @@ extern "C" int gp_destroy(gp_ctx* c) {
   double* bufs[] = {c->Kaug, c->Xmu, c->Xs, c->dir, c->mu, c->S, c->U, c->PU, c->lnc1, c->Xa, c->Z, c->alpha, c->Zaug, c->Zt, reinterpret_cast<double*>(c->gsd), c->gss,
                     c->stats_external ? nullptr : c->stats, c->grads_external ? nullptr : c->grads, c->part, c->klpart, c->Kmm, c->Lmat,
                     c->Linv, c->Inv, c->KmmKeep, c->T1, c->T2, c->dFdK, c->Bbar, c->E, c->PsiE, c->Abar, c->Bm, c->gs, c->gK, c->Rpart,
-                    c->HZp, c->gXmu, c->gXs, c->gapart, c->hgpart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
+                    c->HZp, c->gXmu, c->gXs, c->gapart, c->hgpart, c->g_latest, c->g_new, c->g_old, c->LE, c->LET, c->Bbar4, c->Vn, c->Wn, c->V2P, c->ZP, c->Z1P, c->WP, c->MUP, c->alphaP, c->lnc2h, c->DZ2,
                     c->Gpart, c->Gtmp, c->gapart2, c->pp, c->Z1S, c->ppt, c->Gt, c->spack, c->gen_T, c->gen_rt};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->tiles) (void)hipFree(c->tiles);

@@ -130,6 +130,7 @@ struct gp_ctx {
   double* T2 = nullptr;       // [Mp][Mp] scratch
   double* dFdK = nullptr;     // [Mp][Mp]
   double* Bbar = nullptr;     // [Mp][Mp]
+  double* Bbar4 = nullptr;    // free embeddings, Q <= 16: Bbar with four ROWS interleaved, element (m, m') at ((m / 4) Mp + m') 4 + m % 4 (csrc/psi2.hip)
   double* E = nullptr;        // [Mp][Dp]
   double* PsiE = nullptr;     // [Mp][Dp]
   double* Abar = nullptr;     // [Mp][Dp]

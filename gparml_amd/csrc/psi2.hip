@@ -357,6 +357,17 @@ int psi2_zero_pads(gp_ctx* c) {
 }
 
 // ---------------------------------------------------------------------------------------------- phase 2
+// Bbar with four rows interleaved: element (m, m') at ((m / 4) Mp + m') 4 + m % 4.  The phase-2 kernels below walk down the rows of a lane's column four (two)
+// at a time: one 16-byte load per TWO rows instead of an 8-byte load per row -- the vector-memory instruction count is what the texture addresser prices
+// (16 cycles per wave-instruction whatever its width; profiles/r06_gplvm_experiments.txt items 16, 17).
+__global__ void __launch_bounds__(256) bbar_interleave_kernel(const double* __restrict__ Bbar, int Mp, double* __restrict__ B4) {
+  const long total = (long)Mp * Mp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long m = i / Mp, mc = i - m * Mp;
+    B4[(((m >> 2) * Mp + mc) << 2) + (m & 3)] = Bbar[i];
+  }
+}
+
 // T_n = Bbar o psi2_n (symmetric M x M per point), r_n = T_n 1, t_n = T_n Z give the psi2 parts of every gradient:
 //   grad_Z psi2 part  G[m,k] += -a_k z_mk r + a_k t_k + w_k (2 mu_k r - z_mk r - t_k)          (partial_terms.py:190-205, x2 at :238)
 //   per point: sr, zr_q, z2r_q, zt_q -> quad = 4 mu^2 sr - 8 mu zr + 2 z2r + 2 zt
@@ -384,6 +395,8 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 // Four waves per SIMD (128 VGPRs) up to QT = 14: r06, same box, phase 2 per 1e5 points at M = 512: Q = 13 / 14 44.7 / 45.1 -> 42.1 / 42.5 ms (the cap costs QT = 12 / 14
 // 20 / 28 B of scratch per lane -- values spilled in the prologue and reloaded once per POINT, outside the row loop -- and buys a fourth wave: FP64 issue 6.0 -> 5.6
 // cycles); QT = 16 gains nothing from it (47.6 -> 47.2) and keeps its 167 registers without scratch.
+// which instantiations of psi2_cols_kernel read the row-interleaved Bbar (QT = 8 came out with a 36-byte scratch allocation with it and keeps the plain table)
+__host__ __device__ constexpr bool cols_b4(int QT) { return QT <= 10 && QT != 8; }
 template <int QT, bool KEEP>
 __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Bbar,
                                                         const double* __restrict__ LEA, const double* __restrict__ V2P,
@@ -414,14 +427,21 @@ __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Arg
       for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * (KEEP ? z[q] : ZP[(long)mc * QT + q]); t[q] = 0.0; }
       const double* lrow = LEA + n * a.Mp;               // wave-uniform row of this point
       const double lea = lrow[mc];
-      const double* bcol = Bbar + mc;
+      constexpr bool B4 = cols_b4(QT);                   // Bbar with four rows interleaved (launch_cols passes that table): one 16-byte load per two rows; from QT = 12 on
+      const double* bcol = Bbar + (B4 ? 4 * mc : mc);    // (two rows per trip) it measured 1.2-1.4 % slower than the plain row-major table: profiles/r06_gplvm_experiments.txt item 17
       constexpr int U = QT <= 10 ? 4 : 2;   // rows per trip: U z-rows (2 QT SGPRs each) must fit the scalar file
       // (r06: Bbar of the next trip's rows requested one trip ahead, as psi2_sym_kernel does, for QT > 10 where registers are to spare: slower -- phase 2
       // 42.2 -> 43.6 / 45.7 -> 47.9 / 48.2 -> 65.9 ms per 1e5 points at Q = 12 / 14 / 16; the loop is bound by FP64 issue, not by that latency)
       for (int m = 0; m < Mr; m += U) {
         double bb[U];
+        if constexpr (B4) {
+          const double* b4 = bcol + (long)(m >> 2) * a.Mp * 4;                  // m is a multiple of four
+          const double2 x = *reinterpret_cast<const double2*>(b4), y = *reinterpret_cast<const double2*>(b4 + 2);
+          bb[0] = x.x; bb[1] = x.y; bb[U - 2] = y.x; bb[U - 1] = y.y;
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) bb[u] = bcol[(long)(m + u) * a.Mp];
+          for (int u = 0; u < U; ++u) bb[u] = bcol[(long)(m + u) * a.Mp];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const double* zm = ZP + (long)(m + u) * QT;    // wave-uniform
@@ -547,7 +567,7 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
 #pragma unroll
         for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * ZP[(long)mc * QT + q]; t[q] = 0.0; }
         const double lea = lrow[mc];
-        const double* bcol = Bbar + mc;
+        const double* bcol = Bbar + 4 * mc;                // Bbar4: four rows of this column side by side
         // the row side's B operand [Z | 1] of slab J: 4 NQ values per lane, in registers for the whole tile
         double ZB[4][NQ];
         const double* zbp = Z1S + (long)(64 * J + 16 * lk + 4 * lb) * RT + lq;
@@ -562,7 +582,7 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
         double bbn[4];
         if (BPF) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(64 * I + u) * a.Mp];
+          for (int u = 0; u < 4; u += 2) { const double2 x = *reinterpret_cast<const double2*>(bcol + (long)(16 * I) * a.Mp * 4 + u); bbn[u] = x.x; bbn[u + 1] = x.y; }
         }
         for (int g = 0; g < 16; ++g) {
           const int m0 = 64 * I + 4 * g;
@@ -572,11 +592,11 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
             for (int u = 0; u < 4; ++u) bb[u] = bbn[u];
             if (g + 1 < 16) {
 #pragma unroll
-              for (int u = 0; u < 4; ++u) bbn[u] = bcol[(long)(m0 + 4 + u) * a.Mp];
+              for (int u = 0; u < 4; u += 2) { const double2 x = *reinterpret_cast<const double2*>(bcol + (long)((m0 + 4) >> 2) * a.Mp * 4 + u); bbn[u] = x.x; bbn[u + 1] = x.y; }
             }
           } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bb[u] = bcol[(long)(m0 + u) * a.Mp];
+            for (int u = 0; u < 4; u += 2) { const double2 x = *reinterpret_cast<const double2*>(bcol + (long)(m0 >> 2) * a.Mp * 4 + u); bb[u] = x.x; bb[u + 1] = x.y; }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -735,6 +755,7 @@ int ensure_regime_b_buffers(gp_ctx* c) {
   c->nslab = (int)((M + 63) / 64);
   c->ppb = (int)std::max<long>(16, (c->N + 4095) / 4096);
   c->pb_blocks = (int)((c->N + c->ppb - 1) / c->ppb);
+  A(&c->Bbar4, (size_t)Mp * Mp);
   A(&c->Gpart, (size_t)c->pb_blocks * M * Q); A(&c->gapart2, (size_t)c->pb_blocks * Q); A(&c->Gtmp, (size_t)64 * M * Q);
   std::vector<int> t;
   const int Mt = (int)((M + 15) / 16);
@@ -893,10 +914,10 @@ int run_phase1_b(gp_ctx* c) {
 }
 
 template <int QT, bool KEEP>
-static void launch_cols(gp_ctx* c, const PB2Args& a) {
+static void launch_cols(gp_ctx* c, const PB2Args& a) {     // (the Bbar argument: the row-interleaved table up to QT = 10, the plain one beyond)
   const int nw = std::min(4, c->nslab);
   hipLaunchKernelGGL((psi2_cols_kernel<QT, KEEP>), dim3(c->pb_blocks, (c->nslab + nw - 1) / nw), dim3(64 * nw), 0, c->stream, a, (const double*)c->ZP,
-                     (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
+                     (const double*)(cols_b4(QT) ? c->Bbar4 : c->Bbar), (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
                      (const double*)c->alphaP);
 }
 
@@ -905,7 +926,7 @@ static int launch_sym(gp_ctx* c, const PB2Args& a) {
   const size_t smem = (size_t)c->Mp * sym_rs(QT) * sizeof(double);
   GP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(psi2_sym_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((psi2_sym_kernel<QT>), dim3(c->pb_blocks), dim3(64 * c->sym_nw), smem, c->stream, a, (const double*)c->ZP, (const double*)c->Z1S,
-                     (const double*)c->Bbar, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
+                     (const double*)c->Bbar4, (const double*)c->LET, (const double*)c->V2P, (const double*)c->WP, (const double*)c->MUP,
                      (const double*)c->alphaP, (const int*)c->sym_sched, c->sym_rounds);
   return GP_OK;
 }
@@ -916,6 +937,8 @@ int run_phase2_b(gp_ctx* c) {
   a.Wn = c->Wn; a.mu = c->mu; a.S = c->S; a.alpha = c->alpha;
   a.Gpart = c->Gpart; a.gapart2 = c->gapart2; a.gmu = c->gXmu; a.gS = c->gXs; a.pp = c->pp;
   a.N = c->N; a.Np = c->Np; a.M = c->M; a.Mp = c->Mp; a.Q = c->Q; a.QB = c->QB; a.nslab = c->nslab; a.ppb = c->ppb; a.ngrp = (c->nslab + std::min(4, c->nslab) - 1) / std::min(4, c->nslab);
+  if (!b_generic(c)) hipLaunchKernelGGL(bbar_interleave_kernel, dim3((unsigned)std::min<long>(((long)c->Mp * c->Mp + 255) / 256, 2048)), dim3(256), 0, c->stream,
+                                        (const double*)c->Bbar, c->Mp, c->Bbar4);
   GP_EV(c, 12);   // gp_last_timings' "p2 kernel" slot: in regime B the T_n = Bbar o psi2_n kernel
   if (b_generic(c)) {
     a.ngrp = 1;
@@ -929,8 +952,7 @@ int run_phase2_b(gp_ctx* c) {
     case 4: launch_cols<4, true>(c, a); break;
     case 6: launch_cols<6, true>(c, a); break;
     case 8: launch_cols<8, true>(c, a); break;
-    // (<10, true> is the library's one kernel with a scratch allocation: 16 B per lane, two values spilled in the prologue and reloaded once per point, outside the
-    // row loop.  The scratch-free <10, false> form -- z re-read and grad_Z accumulated in memory per point -- is slower: same box, N = 1e5, M = 128: 2.75 -> 2.98 ms,
+    // (the <10, false> form -- z re-read and grad_Z accumulated in memory per point -- is slower than <10, true>: same box, N = 1e5, M = 128: 2.75 -> 2.98 ms,
     // M = 1024 (5e4 points): 69.2 -> 69.9 ms; profiles/r06_gplvm_experiments.txt)
     case 10: launch_cols<10, true>(c, a); break;
     case 12: launch_cols<12, false>(c, a); break;

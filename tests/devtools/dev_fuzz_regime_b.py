@@ -79,6 +79,24 @@ while done < ncase:
                     # draws the same line): not counted.  The two device paths differ by rounding order only, amplified by the same cancellation (~ cond x 1e-16).
                     flag = False
                     note += ' -> conditioning, not counted'
+                elif M <= 320 and N <= 1200 and max(errs, key=errs.get) == 'grad_Z':
+                    # below that line: who is right?  The bound restated in 80-bit long double (dev_case_truth.F_ld) and differentiated along ONE random direction U by
+                    # central differences (two evaluations): <grad_Z, U> of the library and of the float64 oracle against it (r06: the oracle's K_mm^-1 Psi2 K_mm^-1
+                    # in plain float64 was the outlier in every case arbitrated this way: profiles/r06_fuzz_shapes.txt, r06_fuzz_regime_b.txt)
+                    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+                    from dev_case_truth import F_ld
+                    LD = np.longdouble
+                    U = np.random.RandomState(5).randn(M, Q)
+                    h = LD(1e-5)
+                    Zl = np.asarray(d['Z'], dtype=LD)
+                    fd = float((F_ld(Zl + h * U, d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S']) -
+                                F_ld(Zl - h * U, d['sf2'], d['alpha'], d['beta'], d['Y'], d['X_mu'], d['X_S'])) / (2 * h))
+                    sc = float(np.sum(np.abs(np.asarray(ref['grad_Z']) * U)))
+                    e_lib, e_ora = abs(float(np.sum(out['grad_Z'] * U)) - fd) / sc, abs(float(np.sum(ref['grad_Z'] * U)) - fd) / sc
+                    note += ' | <grad_Z, U> against the long-double bound: library %.1e, oracle %.1e' % (e_lib, e_ora)
+                    if e_lib <= max(1e-6, e_ora):
+                        flag = False
+                        note += ' -> the oracle is the outlier, not counted'
             else:
                 note = ' cond=%.1e | column-kernel child failed: %s' % (cond, r.stderr[-200:])
         print('%s N=%d D=%d M=%d Q=%d alpha=%.2f  F=%.1e worst=%.1e %s%s' % ('BAD ' if flag else ('ok  ' if not note else 'COND'), N, D, M, Q, alpha, abs(out['F'] - ref['F']) / abs(ref['F']), worst,

@@ -185,7 +185,11 @@ __global__ void __launch_bounds__(256) psi2_pairs_kernel(const double* __restric
       const char* grp = reinterpret_cast<const char*>(LE + (n >> 2) * Mp * 4);
       asm volatile("" : "+v"(o1), "+v"(o2));
       const double2 a0 = *reinterpret_cast<const double2*>(grp + o1), a1 = *reinterpret_cast<const double2*>(grp + o1 + 16);
+#ifdef GPARML_PAIRS_HALFLOADS   // timing build (WRONG results): the column side's two loads dropped -- what would two instead of four vector loads per trip buy?
+      const double2 b0 = a0, b1 = a1;
+#else
       const double2 b0 = *reinterpret_cast<const double2*>(grp + o2), b1 = *reinterpret_cast<const double2*>(grp + o2 + 16);
+#endif
       e[0] = a0.x + b0.x; e[1] = a0.y + b0.y; e[2] = a1.x + b1.x; e[3] = a1.y + b1.y;
     }
 #pragma unroll

@@ -530,10 +530,11 @@ __global__ void __launch_bounds__(256, QT <= 14 ? 4 : 2) psi2_cols_kernel(PB2Arg
 // (profiles/r06_gplvm_experiments.txt).
 // the "register diet" (r06): compact rt rows, no one-group-ahead request of Bbar, the four rows of a group two at a time, the finish in two passes.  QT = 12 needs it to
 // exist at all; QT = 8 gets a fourth workgroup per CU from it (rt 36 KB, 96 VGPRs): phase 2 30.5 -> 28.0 ms per 1e5 points at Q = 8, 30.5 -> 27.5 at Q = 7 (same box).
-// QT <= 6: a fifth workgroup per CU (28.7 KB of rt, 82 VGPRs): 24.1 -> 23.4 ms at Q = 6.  QT = 10 -- the one width where compact rows do not buy a workgroup (45 KB) -- keeps the
-// round-3 layout: the diet's pieces measured neutral there, and moving r out of LDS to get to 40 KB cost 11 % (profiles/r06_gplvm_experiments.txt).
-__host__ __device__ constexpr bool sym_diet(int QT) { return QT != 10; }
-__host__ __device__ constexpr int sym_rs(int QT) { return sym_diet(QT) ? QT + 1 : (QT + 1 + 3) / 4 * 4; }
+// QT <= 6: a fifth workgroup per CU (28.7 KB of rt, 82 VGPRs): 24.1 -> 23.4 ms at Q = 6.  QT = 10 -- the one width where compact rows do not buy a workgroup (45 KB) -- kept the
+// round-3 layout (one-group-ahead request of Bbar, padded rows, one finish pass: 167 VGPRs) while the diet's pieces measured neutral there; with Bbar read through the
+// row-interleaved table (one 16-byte load per two rows) they pay: 114 VGPRs, no scratch, phase 2 30.3 -> 29.5 ms per 1e5 points at Q = 10, 30.4 -> 29.2 at Q = 9 (same box,
+// profiles/r06_gplvm_experiments.txt item 18).  Every width runs the diet now.
+__host__ __device__ constexpr int sym_rs(int QT) { return QT + 1; }
 
 template <int QT>
 __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym_kernel(PB2Args a, const double* __restrict__ ZP, const double* __restrict__ Z1S,
@@ -582,26 +583,11 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
 #pragma unroll
             for (int qq = 0; qq < NQ; ++qq) ZB[v][qq] = (ONESQ && qq == NQ - 1) ? onesq : zbp[v * RT + 4 * qq];
         }
-        constexpr bool BPF = !sym_diet(QT);                  // Bbar of the next group of rows one group ahead (QT = 12: no registers left for it)
-        double bbn[4];
-        if (BPF) {
-#pragma unroll
-          for (int u = 0; u < 4; u += 2) { const double2 x = *reinterpret_cast<const double2*>(bcol + (long)(16 * I) * a.Mp * 4 + u); bbn[u] = x.x; bbn[u + 1] = x.y; }
-        }
         for (int g = 0; g < 16; ++g) {
           const int m0 = 64 * I + 4 * g;
           double bb[4], T[4];
-          if (BPF) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bb[u] = bbn[u];
-            if (g + 1 < 16) {
-#pragma unroll
-              for (int u = 0; u < 4; u += 2) { const double2 x = *reinterpret_cast<const double2*>(bcol + (long)((m0 + 4) >> 2) * a.Mp * 4 + u); bbn[u] = x.x; bbn[u + 1] = x.y; }
-            }
-          } else {
-#pragma unroll
-            for (int u = 0; u < 4; u += 2) { const double2 x = *reinterpret_cast<const double2*>(bcol + (long)(m0 >> 2) * a.Mp * 4 + u); bb[u] = x.x; bb[u + 1] = x.y; }
-          }
+          for (int u = 0; u < 4; u += 2) { const double2 x = *reinterpret_cast<const double2*>(bcol + (long)(m0 >> 2) * a.Mp * 4 + u); bb[u] = x.x; bb[u + 1] = x.y; }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const double* zm = ZP + (long)(m0 + u) * QT;    // wave-uniform: scalar loads (an explicit one-row-ahead request of
@@ -613,7 +599,7 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
 #pragma unroll
             for (int q = 0; q < QT; ++q) t[q] = fma(T[u], zm[q], t[q]);
             // QT = 12: the four rows two at a time (four interleaved exp chains with their temporaries do not fit next to 2 x 24 + 26 long-lived registers)
-            if (sym_diet(QT) && u == 1) __builtin_amdgcn_sched_barrier(0);
+            if (u == 1) __builtin_amdgcn_sched_barrier(0);
           }
           if (offd) {
             double acc[NQ];
@@ -621,7 +607,7 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
             if (lb == 0) {
               double* dst = rt + (m0 + lk) * RS + lq;
 #pragma unroll
-              for (int qq = 0; qq < NQ; ++qq) if (RS == RT || 4 * qq + lq <= QT) dst[4 * qq] += acc[qq];      // (compact stride: features beyond the ones column do not exist)
+              for (int qq = 0; qq < NQ; ++qq) if (4 * qq + lq <= QT) dst[4 * qq] += acc[qq];      // (compact stride: features beyond the ones column do not exist)
             }
           }
         }
@@ -638,7 +624,7 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
     const double* mun = MUP + n * QT;
     // QC latent dimensions at a time (all of them up to QT = 10; six at QT = 12, where the 3 QT running sums of one pass did not fit the registers): the rows' r stays
     // in place until the last pass
-    constexpr int QC = sym_diet(QT) ? QT / 2 : QT;
+    constexpr int QC = QT / 2;
     static_assert(QT % QC == 0, "q chunks");
     double* ppw = a.pp + (long)wave * PW * a.Np + n;
     static_for<0, QT / QC>([&](auto cc) {

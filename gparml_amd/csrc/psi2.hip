@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(512, QT == 8 ? 4 : (QT <= 6 ? 5 : 3)) psi2_sym
         double zz[QT], t[QT], r = 0.0;
 #pragma unroll
         for (int q = 0; q < QT; ++q) { zz[q] = v2[q] * ZP[(long)mc * QT + q]; t[q] = 0.0; }
-        const double lea = lrow[mc];
+        const double lea = lrow[mc];     // (r06 timing build with these per-tile loads dropped: no faster -- their latency is hidden behind the other waves)
         const double* bcol = Bbar + 4 * mc;                // Bbar4: four rows of this column side by side
         // the row side's B operand [Z | 1] of slab J: 4 NQ values per lane, in registers for the whole tile
         double ZB[4][NQ];

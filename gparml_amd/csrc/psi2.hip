@@ -398,7 +398,8 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 
 // Four waves per SIMD (128 VGPRs) up to QT = 14: r06, same box, phase 2 per 1e5 points at M = 512: Q = 13 / 14 44.7 / 45.1 -> 42.1 / 42.5 ms (the cap costs QT = 12 / 14
 // 20 / 28 B of scratch per lane -- values spilled in the prologue and reloaded once per POINT, outside the row loop -- and buys a fourth wave: FP64 issue 6.0 -> 5.6
-// cycles); QT = 16 gains nothing from it (47.6 -> 47.2) and keeps its 167 registers without scratch.
+// cycles); QT = 16 gains nothing from it (47.6 -> 47.2; re-measured with the reduce-scatter sums: 47.7 -> 47.4 at M = 512 with 12 B of scratch, 3.96 -> 4.12
+// at M = 128) and keeps its 164 registers without scratch.
 // which instantiations of psi2_cols_kernel read the row-interleaved Bbar (QT = 8 came out with a 36-byte scratch allocation with it and keeps the plain table)
 __host__ __device__ constexpr bool cols_b4(int QT) { return QT <= 10 && QT != 8; }
 template <int QT, bool KEEP>
